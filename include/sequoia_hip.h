@@ -1,0 +1,100 @@
+/* libsequoia_hip.so -- C ABI of the MI355X-native SEQUOIA hot path.
+ *
+ * The reference (gevaertlab/sequoia-pub) has no FFI / plugin interface: the path is
+ * reached through three Python object interfaces.  Each entry
+ * point below states the reference interface it stands behind (file:line under
+ * /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions: every function returns 0 on success and a negative code on error
+ * (message: sq_last_error(), thread-local).  Nothing here allocates device memory:
+ * the caller (PyTorch-ROCm is only the allocator) passes raw device pointers,
+ * element counts and a workspace whose size is queried with *_workspace_bytes.
+ * Every call is asynchronous on the given hipStream_t.  Plain C types only.
+ */
+#ifndef SEQUOIA_HIP_H
+#define SEQUOIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sq_stream_t; /* hipStream_t */
+
+#define SQ_DTYPE_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
+#define SQ_DTYPE_BF16 1 /* bf16 MFMA, fp32 accumulate: perf mode              */
+
+#define SQ_MAX_DEPTH 16
+#define SQ_HEAD_DIM 64 /* dimensions_f = dimensions_s = dimensions_c = 64 (src/main.py:147,167,202) */
+
+const char* sq_last_error(void);
+int sq_version(void);
+/* 1 when a gfx950 device is visible to the HIP runtime, else 0 (never fails) */
+int sq_device_ok(void);
+
+/* ------------------------------------------------------------------------------
+ * ViS aggregator  (src/tformer_lin.py:80-106 ViS; :64-77 SummaryTransformer;
+ * :29-48 MultiHeadSummary; :7-26 SummaryMixing; :51-61 FeedForward)
+ * ---------------------------------------------------------------------------- */
+typedef struct sq_vis_config {
+    int32_t input_dim;    /* D: 1024 (UNI) or 2048 (ResNet-50); multiple of 64 */
+    int32_t depth;        /* main.py:36 default 6 */
+    int32_t nheads;       /* main.py:37 default 16 */
+    int32_t num_outputs;  /* G = 20820 genes */
+    int32_t num_clusters; /* 100 tokens (tformer_lin.py:83) */
+} sq_vis_config;
+
+/* Offsets (in elements) of every reference tensor inside ONE flat parameter buffer.
+ * Per-head tensors are stored head-major and contiguous, so each reference tensor
+ * `transformer.layers.{l}.0.mixers.{h}.f.weight` etc. is a contiguous slice. */
+typedef struct sq_vis_layer_offsets {
+    int64_t f_w, f_b;       /* mixers.{h}.f.{weight,bias}              [H][64][D], [H][64] */
+    int64_t s_w, s_b;       /* mixers.{h}.s.{weight,bias}              [H][64][D], [H][64] */
+    int64_t lnf_g, lnf_b;   /* mixers.{h}.local_norm.{weight,bias}     [H][64]             */
+    int64_t lns_g, lns_b;   /* mixers.{h}.summary_norm.{weight,bias}   [H][64]             */
+    int64_t c_w, c_b;       /* mixers.{h}.c.{weight,bias}              [H][64][128], [H][64] */
+    int64_t proj_w, proj_b; /* projection.{weight,bias}                [D][H*64], [D]      */
+    int64_t ffln_g, ffln_b; /* net.0 LayerNorm(D)                                           */
+    int64_t ff1_w, ff1_b;   /* net.1 Linear(D, D)                                           */
+    int64_t ff2_w, ff2_b;   /* net.3 Linear(D, D)                                           */
+} sq_vis_layer_offsets;
+
+typedef struct sq_vis_layout {
+    int64_t pos;                  /* pos_emb1D [num_clusters][D] */
+    int64_t head_ln_g, head_ln_b; /* linear_head.0 */
+    int64_t head_w, head_b;       /* linear_head.1 [G][D], [G] */
+    int64_t total;                /* elements in the flat buffer */
+    sq_vis_layer_offsets layer[SQ_MAX_DEPTH];
+} sq_vis_layout;
+
+int sq_vis_layout_init(const sq_vis_config* cfg, sq_vis_layout* out);
+
+size_t sq_vis_workspace_bytes(const sq_vis_config* cfg, int dtype, int batch, int save_for_backward);
+
+/* ViS.forward (tformer_lin.py:97-106): x f32 [B, num_clusters, D] -> out f32 [B, G].
+ * params: flat fp32 buffer (sq_vis_layout); params_lp: bf16 copy of the same buffer
+ * (dtype == SQ_DTYPE_BF16) or NULL.  save_for_backward keeps the per-layer activations
+ * sq_vis_backward needs in the workspace. */
+int sq_vis_forward(const sq_vis_config* cfg, int dtype, const float* params, const void* params_lp, const float* x,
+                   float* out, int batch, int save_for_backward, void* workspace, size_t workspace_bytes,
+                   sq_stream_t stream);
+
+/* dst_bf16[i] = bf16(src[i]) -- refresh of the bf16 parameter shadow after an optimizer step */
+int sq_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, sq_stream_t stream);
+
+/* ------------------------------------------------------------------------------
+ * Fused linear layer  C = act(A . W^T + bias + residual)   -- the nn.Linear call sites of
+ * src/tformer_lin.py:14-16,37,55,57,93 and the 1x1 convolutions of src/resnet.py:60,66.
+ * A [M,K] (lda) and W [N,K] (ldw) are `dtype` (f32 or bf16), bias f32 [N] or NULL,
+ * residual f32 [M,N] (ldres) or NULL, act: 0 none, 1 exact-erf GELU, 2 ReLU,
+ * C [M,N] (ldc) in out_dtype.  K, lda, ldw multiples of 16 bytes / element size.
+ * ---------------------------------------------------------------------------- */
+int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual,
+              int ldres, int act, void* C, int out_dtype, int ldc, int M, int N, int K, sq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQUOIA_HIP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of libsequoia_hip.so (the C ABI in include/sequoia_hip.h).
+
+PyTorch is imported first on purpose: the library's NEEDED ``libamdhip64.so.7`` then
+resolves to the HIP runtime PyTorch-ROCm already loaded, so device pointers and
+streams are shared.  There is no fallback: a missing library or GPU raises.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsequoia_hip.so")
+
+SQ_F32 = 0
+SQ_BF16 = 1
+SQ_MAX_DEPTH = 16
+HEAD_DIM = 64
+
+DTYPES = {"fp32": SQ_F32, "f32": SQ_F32, "float32": SQ_F32, SQ_F32: SQ_F32,
+          "bf16": SQ_BF16, "bfloat16": SQ_BF16, SQ_BF16: SQ_BF16}
+
+
+class VisConfig(ctypes.Structure):
+    _fields_ = [("input_dim", ctypes.c_int32), ("depth", ctypes.c_int32), ("nheads", ctypes.c_int32),
+                ("num_outputs", ctypes.c_int32), ("num_clusters", ctypes.c_int32)]
+
+
+_LAYER_FIELDS = ["f_w", "f_b", "s_w", "s_b", "lnf_g", "lnf_b", "lns_g", "lns_b", "c_w", "c_b",
+                 "proj_w", "proj_b", "ffln_g", "ffln_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b"]
+
+
+class VisLayerOffsets(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in _LAYER_FIELDS]
+
+
+class VisLayout(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_int64), ("head_ln_g", ctypes.c_int64), ("head_ln_b", ctypes.c_int64),
+                ("head_w", ctypes.c_int64), ("head_b", ctypes.c_int64), ("total", ctypes.c_int64),
+                ("layer", VisLayerOffsets * SQ_MAX_DEPTH)]
+
+
+class SequoiaHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.sq_last_error.restype = ctypes.c_char_p
+    lib.sq_last_error.argtypes = []
+    lib.sq_version.restype = i32
+    lib.sq_device_ok.restype = i32
+    lib.sq_vis_layout_init.restype = i32
+    lib.sq_vis_layout_init.argtypes = [ctypes.POINTER(VisConfig), ctypes.POINTER(VisLayout)]
+    lib.sq_vis_workspace_bytes.restype = sz
+    lib.sq_vis_workspace_bytes.argtypes = [ctypes.POINTER(VisConfig), i32, i32, i32]
+    lib.sq_vis_forward.restype = i32
+    lib.sq_vis_forward.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, i32, i32, vp, sz, vp]
+    lib.sq_linear.restype = i32
+    lib.sq_linear.argtypes = [i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]
+    lib.sq_cast_f32_to_bf16.restype = i32
+    lib.sq_cast_f32_to_bf16.argtypes = [vp, vp, sz, vp]
+    for name, (res, args) in _OPTIONAL.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+
+
+_OPTIONAL = {}
+
+
+def register_signature(name, restype, argtypes):
+    """Let sibling modules declare the entry points they bind (kept next to their use)."""
+    _OPTIONAL[name] = (restype, argtypes)
+    if _lib is not None and hasattr(_lib, name):
+        fn = getattr(_lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SequoiaHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or sequoia-pub_amd/csrc/build.sh).  sequoia-pub_amd has no CPU fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SequoiaHipError(f"libsequoia_hip error {rc}: {lib().sq_last_error().decode()}")
+
+
+def require_gpu(device=None):
+    """The product path runs on MI355X only: fail loudly otherwise."""
+    if not torch.cuda.is_available():
+        raise SequoiaHipError("no ROCm GPU visible to PyTorch: the HIP path cannot run (and there is no CPU fallback)")
+    if not lib().sq_device_ok():
+        raise SequoiaHipError("the visible GPU is not gfx950 (MI355X); libsequoia_hip is built for gfx950 only")
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

@@ -1,0 +1,223 @@
+// Memory-bound helper kernels (gfx950): 16-byte accesses per lane, wave64 reductions.
+#include "elementwise.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+__global__ void add_pos_kernel(const float4* __restrict__ x, const float4* __restrict__ pos, float4* __restrict__ X,
+                               uint2* __restrict__ Xh, size_t total4, size_t nd4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = x[i], p = pos[i % nd4];
+        const float4 v = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        X[i] = v;
+        if (Xh) Xh[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+}
+
+// thread = (b, d4): adds the N token rows in index order (deterministic fp32 order)
+__global__ void token_mean_kernel(const float4* __restrict__ X, float4* __restrict__ out, uint2* __restrict__ outh,
+                                  int B, int N, int D4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D4) return;
+    const int b = i / D4, d = i - b * D4;
+    const float4* p = X + (size_t)b * N * D4 + d;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < N; ++n) {
+        const float4 v = p[(size_t)n * D4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float inv = 1.0f / (float)N;
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    out[i] = acc;
+    if (outh) outh[i] = make_uint2(pack_bf16x2(acc.x, acc.y), pack_bf16x2(acc.z, acc.w));
+}
+
+// one wave per row; row kept in registers between the mean and variance passes
+template <int MAXI>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ b, void* __restrict__ y, int out_bf16,
+                                                      int R, int D, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int D4 = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4 v[MAXI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = i * 64 + lane;
+        if (c < D4) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            q += (a * a + bb * bb) + (cc * cc + dd * dd);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + LN_EPS);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = i * 64 + lane;
+        if (c < D4) {
+            const float4 gg = g4[c], bb = b4[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+            if (out_bf16)
+                reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + (size_t)row * D)[c] =
+                    make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+            else
+                reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (size_t)row * D)[c] = o;
+        }
+    }
+}
+
+// 16 lanes per 64-wide group (4 elements per lane), 4 groups per wave-iteration
+__global__ __launch_bounds__(256) void ln64_gelu_kernel(const float4* __restrict__ x, const float4* __restrict__ g,
+                                                        const float4* __restrict__ b, void* __restrict__ y, int out_bf16,
+                                                        size_t ngroups, int C16) {
+    const int sub = threadIdx.x & 15;
+    for (size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; grp < ngroups;
+         grp += ((size_t)gridDim.x * blockDim.x) >> 4) {
+        const size_t i4 = grp * 16 + sub;           // float4 index
+        const float4 v = x[i4];
+        float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.0f / 64.0f);
+        const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+        float q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
+        const int c4 = (int)(i4 % (size_t)C16);     // float4 column inside the row
+        const float4 gg = g[c4], bb = b[c4];
+        float4 o;
+        o.x = gelu_erf(a0 * rstd * gg.x + bb.x);
+        o.y = gelu_erf(a1 * rstd * gg.y + bb.y);
+        o.z = gelu_erf(a2 * rstd * gg.z + bb.z);
+        o.w = gelu_erf(a3 * rstd * gg.w + bb.w);
+        if (out_bf16) reinterpret_cast<uint2*>(y)[i4] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        else reinterpret_cast<float4*>(y)[i4] = o;
+    }
+}
+
+__global__ void f32_to_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, size_t n4, const float* tail_src,
+                                   bf16_t* tail_dst, int tail) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = gid; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        dst[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+    if (gid < (size_t)tail) tail_dst[gid] = f32_to_bf16(tail_src[gid]);
+}
+
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = bf16_to_f32(src[i]);
+}
+
+// 64x64 tile through LDS (+1 padding), coalesced on both sides
+template <typename E>
+__global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ src, E* __restrict__ dst, int R, int C) {
+    __shared__ E tile[64][65];
+    const size_t boff = (size_t)blockIdx.z * R * C;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < R && c < C) tile[i][tx] = src[boff + (size_t)r * C + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) dst[boff + (size_t)c * R + r] = tile[tx][i];
+    }
+}
+
+inline int grid_for(size_t work_items, int block, int cap = 256 * 8) {
+    size_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+int sq_k_add_pos(const float* x, const float* pos, float* X, bf16_t* Xh, int B, int N, int D, hipStream_t s) {
+    SQ_REQUIRE(D % 4 == 0, "add_pos: D=%d must be a multiple of 4", D);
+    const size_t total4 = (size_t)B * N * D / 4, nd4 = (size_t)N * D / 4;
+    hipLaunchKernelGGL(add_pos_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, s, (const float4*)x, (const float4*)pos,
+                       (float4*)X, (uint2*)Xh, total4, nd4);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_token_mean(const float* X, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s) {
+    SQ_REQUIRE(D % 4 == 0, "token_mean: D=%d must be a multiple of 4", D);
+    const int total = B * (D / 4);
+    hipLaunchKernelGGL(token_mean_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float4*)X, (float4*)out,
+                       (uint2*)outh, B, N, D / 4);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_ln_rows(const float* x, const float* g, const float* b, void* y, int out_dtype, int R, int D, float* mean_out,
+                 float* rstd_out, hipStream_t s) {
+    SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows: D=%d must be a multiple of 4 and <= 4096", D);
+    const dim3 grid((R + 3) / 4), block(256);
+    const int ob = out_dtype == SQ_BF16;
+    if (D <= 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+    else if (D <= 2048) hipLaunchKernelGGL(ln_rows_kernel<8>, grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+    else hipLaunchKernelGGL(ln_rows_kernel<16>, grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_ln64_gelu(const float* x, const float* g, const float* b, void* y, int out_dtype, int R, int C, hipStream_t s) {
+    SQ_REQUIRE(C % 64 == 0, "ln64_gelu: C=%d must be a multiple of 64", C);
+    const size_t ngroups = (size_t)R * (C / 64);
+    hipLaunchKernelGGL(ln64_gelu_kernel, dim3(grid_for(ngroups * 16, 256)), dim3(256), 0, s, (const float4*)x,
+                       (const float4*)g, (const float4*)b, y, out_dtype == SQ_BF16, ngroups, C / 4);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
+    const size_t n4 = n / 4;
+    const int tail = (int)(n - n4 * 4);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n4 ? n4 : 1, 256)), dim3(256), 0, s, (const float4*)src, (uint2*)dst,
+                       n4, src + n4 * 4, dst + n4 * 4, tail);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_bf16_to_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_transpose(const void* src, void* dst, int R, int C, int elem_size, int batch, hipStream_t s) {
+    const dim3 grid((C + 63) / 64, (R + 63) / 64, batch), block(256);
+    if (elem_size == 2) hipLaunchKernelGGL(transpose_kernel<uint16_t>, grid, block, 0, s, (const uint16_t*)src, (uint16_t*)dst, R, C);
+    else if (elem_size == 4) hipLaunchKernelGGL(transpose_kernel<uint32_t>, grid, block, 0, s, (const uint32_t*)src, (uint32_t*)dst, R, C);
+    else { sq_set_error("transpose: elem_size %d", elem_size); return SQ_ERR_ARG; }
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}

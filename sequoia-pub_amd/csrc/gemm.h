@@ -1,0 +1,33 @@
+// MFMA "NT" GEMM engine of libsequoia_hip:  C[M,N] = act(A[M,K] . B[N,K]^T + bias + rowbias + res)
+// Both operands are K-contiguous (activations row-major, nn.Linear / packed conv weights
+// [out, in]).  A can also be an implicit-GEMM view of an NHWC activation (conv taps).
+#pragma once
+#include "sq_common.h"
+
+#define SQ_ACT_NONE 0
+#define SQ_ACT_GELU 1
+#define SQ_ACT_RELU 2
+
+struct GemmArgs {
+    const void* A = nullptr;      // [M, K] (lda) in T, or NHWC activation when conv != 0
+    const void* B = nullptr;      // [N, K] (ldb) in T
+    void* C = nullptr;            // [M, N] (ldc) f32 or bf16 (out_dtype)
+    bf16_t* C2 = nullptr;         // optional bf16 copy of C (ldc2)
+    float* Cpre = nullptr;        // optional f32 copy of the pre-activation value (ldpre)
+    const float* bias = nullptr;      // [N]
+    const float* rowbias = nullptr;   // [ceil(M / rows_per_group), N] (ldrb)
+    const void* res = nullptr;        // [M, N] (ldres) f32 or bf16 (res_dtype)
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldb = 0, ldc = 0, ldc2 = 0, ldpre = 0, ldres = 0, ldrb = 0;
+    int rows_per_group = 1;
+    int act = SQ_ACT_NONE;
+    int out_dtype = SQ_F32, res_dtype = SQ_F32;
+    int batch = 1;
+    long long sA = 0, sB = 0, sC = 0, sC2 = 0, sPre = 0, sBias = 0, sRb = 0, sRes = 0;   // per-batch strides (elements)
+    // implicit-GEMM convolution view of A: NHWC [n, H, W, Cin]; K = KH*KW*Cin, tap-major
+    int conv = 0, H = 0, W = 0, Cin = 0, OH = 0, OW = 0, KW = 1, stride = 1, pad = 0;
+    size_t a_bytes = 0, b_bytes = 0;   // extents of A and B for the buffer descriptors (< 2 GiB)
+};
+
+// dtype: SQ_F32 (v_mfma_f32_32x32x2_f32, exact fp32) or SQ_BF16 (v_mfma_f32_32x32x16_bf16)
+int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream);

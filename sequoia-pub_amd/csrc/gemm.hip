@@ -1,0 +1,281 @@
+// MFMA NT GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+// Tile: 256 threads = 4 waves (2x2); each wave owns WTM x WTN MFMA tiles of 32x32.
+// K is walked in tiles of 128 bytes per row (64 bf16 / 32 fp32), staged
+// global -> VGPR -> LDS (register prefetch of tile t+1 under the MFMAs of tile t, two
+// LDS buffers, one barrier per K-tile).  LDS rows are 128 B, 16-B chunks XOR-swizzled
+// by (row>>1)&7 so every ds_read_b128 lane group touches 16 distinct 16-B slots.
+// Loads go through buffer descriptors: rows past M/N, K tails and convolution padding
+// are redirected to an out-of-range offset and read back as zero.
+//
+// fp32 path: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) -- the parity mode.
+// bf16 path: v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the perf mode.
+#include "gemm.h"
+
+namespace {
+
+constexpr uint32_t OOB = 0x80000000u;
+
+__device__ __forceinline__ u32x4 lds_read128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+template <typename T> struct Mma;
+
+template <> struct Mma<float> {
+    // chunk = 4 floats: element e of lane-half h is k = 4*(2s+h)+e; A and B use the same
+    // assignment, so the contraction is a permutation of the K-tile.
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& acc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
+    }
+};
+
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& acc) {
+        union { u32x4 u; bf16x8 h; } ua, ub;
+        ua.u = a; ub.u = b;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
+    }
+};
+
+template <typename T, int WTM, int WTN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
+    constexpr int BM = 64 * WTM, BN = 64 * WTN;
+    constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+    constexpr int BK = 8 * EPC;                // K elements per tile (128 B)
+    constexpr int RA = BM / 32, RB = BN / 32;  // chunks per thread per tile
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: each XCD (block id % 8) walks a contiguous run of tiles
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int t;
+    {
+        const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (t / tiles_n) * BM;
+    const int n0 = (t % tiles_n) * BN;
+    const int z = blockIdx.z;
+
+    const T* Ab = reinterpret_cast<const T*>(p.A) + (long long)z * p.sA;
+    const T* Bb = reinterpret_cast<const T*>(p.B) + (long long)z * p.sB;
+    const size_t a_rem = p.a_bytes - (size_t)z * p.sA * sizeof(T);
+    const size_t b_rem = p.b_bytes - (size_t)z * p.sB * sizeof(T);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_rem, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_rem, 0x00020000);
+
+    const int c16 = tid & 7;      // 16-B chunk inside the 128-B K-tile row
+    const int r0 = tid >> 3;      // row inside a 32-row group
+
+    // per-thread row bookkeeping
+    uint32_t a_row_off[RA];       // element offset of the row start (plain) / pixel base (conv)
+    int a_ih0[RA], a_iw0[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int m = m0 + r0 + 32 * j;
+        a_ok[j] = m < p.M;
+        if (p.conv) {
+            const int ohw = p.OH * p.OW;
+            const int img = m / ohw;
+            const int rem = m - img * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih0[j] = oh * p.stride - p.pad;
+            a_iw0[j] = ow * p.stride - p.pad;
+            a_row_off[j] = (uint32_t)(img * p.H * p.W);
+        } else {
+            a_ih0[j] = a_iw0[j] = 0;
+            a_row_off[j] = (uint32_t)m * (uint32_t)p.lda;
+        }
+    }
+    uint32_t b_row_off[RB];
+    bool b_ok[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        b_ok[j] = n < p.N;
+        b_row_off[j] = (uint32_t)n * (uint32_t)p.ldb;
+    }
+
+    u32x4 ra[RA], rb[RB];
+
+    auto issue_loads = [&](int kt) {
+        const int k0 = kt * BK;
+        const int kc = k0 + c16 * EPC;
+        const bool k_ok = kc < p.K;
+        if (p.conv) {
+            const int tap = k0 / p.Cin;            // a K-tile never straddles taps (Cin % BK == 0)
+            const int cin0 = k0 - tap * p.Cin + c16 * EPC;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+                const bool ok = a_ok[j] && k_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const uint32_t off = ((a_row_off[j] + (uint32_t)(ih * p.W + iw)) * (uint32_t)p.Cin + (uint32_t)cin0) * (uint32_t)sizeof(T);
+                ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : OOB, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const uint32_t off = (a_row_off[j] + (uint32_t)kc) * (uint32_t)sizeof(T);
+                ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (a_ok[j] && k_ok) ? off : OOB, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const uint32_t off = (b_row_off[j] + (uint32_t)kc) * (uint32_t)sizeof(T);
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_ok[j] && k_ok) ? off : OOB, 0, 0);
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+        char* sa = smem + buf * TILE_BYTES;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int row = r0 + 32 * j;
+            *reinterpret_cast<u32x4*>(sa + row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int row = r0 + 32 * j;
+            *reinterpret_cast<u32x4*>(sb + row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4)) = rb[j];
+        }
+    };
+
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * TILE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int chunk = 2 * s + lh;
+            u32x4 fa[WTM], fb[WTN];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) {
+                const int row = wm * (WTM * 32) + i * 32 + l31;
+                fa[i] = lds_read128(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                const int row = wn * (WTN * 32) + j * 32 + l31;
+                fb[j] = lds_read128(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    issue_loads(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) issue_loads(kt + 1);
+        compute(kt & 1);
+        if (more) store_lds((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+    const float* rowbias = p.rowbias ? p.rowbias + (long long)z * p.sRb : nullptr;
+    const float* res32 = (p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
+    const bf16_t* res16 = (p.res && p.res_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes : nullptr;
+    float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
+    bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
+    bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
+    float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
+
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+        const int n = n0 + wn * (WTN * 32) + j * 32 + l31;
+        if (n >= p.N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (rowbias) v += rowbias[(long long)(m / p.rows_per_group) * p.ldrb + n];
+                if (res32) v += res32[(long long)m * p.ldres + n];
+                if (res16) v += bf16_to_f32(res16[(long long)m * p.ldres + n]);
+                if (cpre) cpre[(long long)m * p.ldpre + n] = v;
+                if (p.act == SQ_ACT_GELU) v = gelu_erf(v);
+                else if (p.act == SQ_ACT_RELU) v = fmaxf(v, 0.f);
+                if (c32) c32[(long long)m * p.ldc + n] = v;
+                if (c16p) c16p[(long long)m * p.ldc + n] = f32_to_bf16(v);
+                if (c2) c2[(long long)m * p.ldc2 + n] = f32_to_bf16(v);
+            }
+        }
+    }
+}
+
+template <typename T, int WTM, int WTN>
+int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM = 64 * WTM, BN = 64 * WTN;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const size_t lds = 2 * (BM + BN) * 128;
+    dim3 grid(tiles, 1, a.batch), block(256);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN>), grid, block, lds, stream, a);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+template <typename T>
+int launch_t(const GemmArgs& a, hipStream_t stream) {
+    // tile choice: fill >= 256 CUs when the problem allows; narrow N (Cout 64) gets BN = 64
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+    if (a.N <= 64) {
+        if ((long long)((a.M + 127) / 128) * a.batch >= 256) return launch_cfg<T, 2, 1>(a, stream);
+        return launch_cfg<T, 1, 1>(a, stream);
+    }
+    if (a.M <= 64) return launch_cfg<T, 1, 2>(a, stream);
+    if (t128 >= 512) return launch_cfg<T, 2, 2>(a, stream);
+    const long long t64n = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * a.batch;
+    if (t64n >= 384) return launch_cfg<T, 2, 1>(a, stream);
+    return launch_cfg<T, 1, 1>(a, stream);
+}
+
+}  // namespace
+
+int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
+    const int epc = dtype == SQ_BF16 ? 8 : 4;
+    SQ_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    SQ_REQUIRE(a.K % epc == 0 && a.ldb % epc == 0, "gemm: K=%d / ldb=%d must be multiples of %d", a.K, a.ldb, epc);
+    SQ_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0, "gemm: A/B must be 16-byte aligned");
+    SQ_REQUIRE(a.a_bytes > 0 && a.a_bytes < (1ull << 31) && a.b_bytes > 0 && a.b_bytes < (1ull << 31),
+               "gemm: operand extents must be in (0, 2 GiB): %zu %zu", a.a_bytes, a.b_bytes);
+    if (a.conv) {
+        SQ_REQUIRE(a.Cin % (8 * epc) == 0, "conv: Cin=%d must be a multiple of the K-tile (%d)", a.Cin, 8 * epc);
+    } else {
+        SQ_REQUIRE(a.lda % epc == 0, "gemm: lda=%d must be a multiple of %d", a.lda, epc);
+    }
+    if (dtype == SQ_BF16) return launch_t<bf16_t>(a, stream);
+    if (dtype == SQ_F32) return launch_t<float>(a, stream);
+    sq_set_error("gemm: unknown dtype %d", dtype);
+    return SQ_ERR_ARG;
+}

@@ -1,0 +1,95 @@
+// Shared device/host helpers for libsequoia_hip (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define SQ_OK 0
+#define SQ_ERR_ARG -1
+#define SQ_ERR_HIP -2
+#define SQ_ERR_WORKSPACE -3
+#define SQ_ERR_UNSUPPORTED -4
+
+#define SQ_F32 0
+#define SQ_BF16 1
+
+void sq_set_error(const char* fmt, ...);
+
+#define SQ_HIP_CHECK(expr)                                                        \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            sq_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                         __FILE__, __LINE__);                                     \
+            return SQ_ERR_HIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+#define SQ_REQUIRE(cond, ...)                                                     \
+    do {                                                                          \
+        if (!(cond)) {                                                            \
+            sq_set_error(__VA_ARGS__);                                            \
+            return SQ_ERR_ARG;                                                    \
+        }                                                                         \
+    } while (0)
+
+#define SQ_LAUNCH_CHECK()                                                         \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) {                                                   \
+            sq_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                     \
+            return SQ_ERR_HIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+typedef uint16_t bf16_t;   // storage type for bfloat16
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// exact (erf) GELU: torch.nn.GELU() default, tformer_lin.py:20-24,57
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// d/dx of exact GELU
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T> struct sq_type;
+template <> struct sq_type<float> { static constexpr int id = SQ_F32; };
+template <> struct sq_type<bf16_t> { static constexpr int id = SQ_BF16; };
+
+static inline size_t sq_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int sq_dtype_size(int dtype) { return dtype == SQ_BF16 ? 2 : 4; }

@@ -1,0 +1,42 @@
+// ViS (SummaryMixing aggregator) forward/backward sequencing on top of the GEMM engine.
+#pragma once
+#include "../../include/sequoia_hip.h"
+#include "sq_common.h"
+
+struct Arena {
+    char* base;
+    size_t off;
+    void* take(size_t bytes) {
+        off = sq_align_up(off, 256);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+// Workspace of one ViS forward (+ what backward re-reads when save_for_backward).
+// T = compute dtype (f32 or bf16).  M = B*N tokens, HD = nheads*64.
+struct VisBufs {
+    int nsave;                          // depth when saving, else 1
+    float* Xin[SQ_MAX_DEPTH + 1];       // [M, D] f32 layer inputs (index 0 = x + pos); 1 buffer when not saving
+    void* Xin_lp[SQ_MAX_DEPTH + 1];     // bf16 copies (bf16 mode) else == Xin
+    float* X1[SQ_MAX_DEPTH];            // [M, D] f32 after the mixer block
+    void* X1_lp[SQ_MAX_DEPTH];          // bf16 copy (unused by forward, kept for symmetry) or == X1
+    float* Xbar32[SQ_MAX_DEPTH];        // [B, D] f32 token mean
+    void* Xbar[SQ_MAX_DEPTH];           // [B, D] T
+    float* F[SQ_MAX_DEPTH];             // [M, HD] f32  f(x)+b (pre-LN)
+    void* Lf[SQ_MAX_DEPTH];             // [M, HD] T    GELU(LN64(F))
+    float* Sm[SQ_MAX_DEPTH];            // [B, HD] f32  s(mean x)+b (pre-LN)
+    void* Ts[SQ_MAX_DEPTH];             // [B, HD] T    GELU(LN64(Sm))
+    float* Cs[SQ_MAX_DEPTH];            // [B, HD] f32  summary half of the combiner + bias
+    float* P[SQ_MAX_DEPTH];             // [M, HD] f32  combiner pre-activation (saved only when training)
+    void* O[SQ_MAX_DEPTH];              // [M, HD] T    GELU(P)
+    void* Y[SQ_MAX_DEPTH];              // [M, D] T     LayerNorm(X1)
+    float* U[SQ_MAX_DEPTH];             // [M, D] f32   FF pre-activation (saved only when training)
+    void* H1[SQ_MAX_DEPTH];             // [M, D] T     GELU(U)
+    float* xm;                          // [B, D] f32 token mean of the last layer output
+    void* xn;                           // [B, D] T   LayerNorm(xm)
+    size_t bytes;
+};
+
+void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base, VisBufs* out);

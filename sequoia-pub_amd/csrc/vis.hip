@@ -1,0 +1,234 @@
+// ViS forward (src/tformer_lin.py) as a fixed launch sequence over the MFMA GEMM engine.
+//
+// Per layer (M = B*100 tokens, HD = nheads*64):
+//   Xbar = mean_n X                                   [B, D]    token_mean
+//   F    = X . Wf^T + bf        (16 heads as ONE GEMM) [M, HD]   gemm
+//   Lf   = GELU(LN64(F))                               [M, HD]   ln64_gelu        (tformer_lin.py:20)
+//   Sm   = Xbar . Ws^T + bs     (= mean_n s(x): the linear map commutes with the token mean,
+//                                 100x fewer MACs than :21-22)    [B, HD]   gemm
+//   Ts   = GELU(LN64(Sm))                              [B, HD]   ln64_gelu        (:22)
+//   Cs   = Ts_h . Wc_h[:, 64:]^T + bc_h   per head     [B, HD]   batched gemm     (:24, summary half of cat)
+//   O    = GELU(Lf_h . Wc_h[:, :64]^T + Cs[b])         [M, HD]   batched gemm, per-slide row bias (:24)
+//   X1   = O . Wp^T + bp + X                            [M, D]    gemm + residual  (:45-46,75)
+//   Y    = LN_D(X1)                                     [M, D]    ln_rows          (:54)
+//   H1   = GELU(Y . W1^T + b1)                          [M, D]    gemm             (:55-56)
+//   X    = H1 . W2^T + b2 + X1                          [M, D]    gemm + residual  (:57,76)
+// Head:  out = LN_D(mean_n X) . Wh^T + bh               [B, G]                     (:103-106)
+#include "vis.h"
+#include "elementwise.h"
+#include "gemm.h"
+
+void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base, VisBufs* o) {
+    Arena a{base, 0};
+    const size_t es = sq_dtype_size(dtype);
+    const size_t M = (size_t)B * c.num_clusters, D = c.input_dim, HD = (size_t)c.nheads * SQ_HEAD_DIM;
+    const int L = save ? c.depth : 1;
+    o->nsave = L;
+    const int nX = save ? c.depth + 1 : 1;
+    for (int l = 0; l <= SQ_MAX_DEPTH; ++l) {
+        const int src = l < nX ? l : 0;
+        if (l < nX) {
+            o->Xin[l] = (float*)a.take(M * D * 4);
+            o->Xin_lp[l] = dtype == SQ_BF16 ? a.take(M * D * 2) : (void*)o->Xin[l];
+        } else {
+            o->Xin[l] = o->Xin[src];
+            o->Xin_lp[l] = o->Xin_lp[src];
+        }
+    }
+    for (int l = 0; l < SQ_MAX_DEPTH; ++l) {
+        if (l < L) {
+            o->X1[l] = (float*)a.take(M * D * 4);
+            o->X1_lp[l] = o->X1[l];
+            o->Xbar32[l] = (float*)a.take((size_t)B * D * 4);
+            o->Xbar[l] = dtype == SQ_BF16 ? a.take((size_t)B * D * 2) : (void*)o->Xbar32[l];
+            o->F[l] = (float*)a.take(M * HD * 4);
+            o->Lf[l] = a.take(M * HD * es);
+            o->Sm[l] = (float*)a.take((size_t)B * HD * 4);
+            o->Ts[l] = a.take((size_t)B * HD * es);
+            o->Cs[l] = (float*)a.take((size_t)B * HD * 4);
+            o->P[l] = save ? (float*)a.take(M * HD * 4) : nullptr;
+            o->O[l] = a.take(M * HD * es);
+            o->Y[l] = a.take(M * D * es);
+            o->U[l] = save ? (float*)a.take(M * D * 4) : nullptr;
+            o->H1[l] = a.take(M * D * es);
+        } else {
+            o->X1[l] = o->X1[0]; o->X1_lp[l] = o->X1_lp[0]; o->Xbar32[l] = o->Xbar32[0]; o->Xbar[l] = o->Xbar[0];
+            o->F[l] = o->F[0]; o->Lf[l] = o->Lf[0]; o->Sm[l] = o->Sm[0]; o->Ts[l] = o->Ts[0]; o->Cs[l] = o->Cs[0];
+            o->P[l] = o->P[0]; o->O[l] = o->O[0]; o->Y[l] = o->Y[0]; o->U[l] = o->U[0]; o->H1[l] = o->H1[0];
+        }
+    }
+    o->xm = (float*)a.take((size_t)B * D * 4);
+    o->xn = a.take((size_t)B * D * es);
+    o->bytes = sq_align_up(a.off, 256);
+}
+
+static int check_cfg(const sq_vis_config* c) {
+    SQ_REQUIRE(c != nullptr, "vis: null config");
+    SQ_REQUIRE(c->input_dim > 0 && c->input_dim % 64 == 0 && c->input_dim <= 4096, "vis: input_dim=%d must be a multiple of 64, <= 4096", c->input_dim);
+    SQ_REQUIRE(c->depth >= 1 && c->depth <= SQ_MAX_DEPTH, "vis: depth=%d out of [1,%d]", c->depth, SQ_MAX_DEPTH);
+    SQ_REQUIRE(c->nheads >= 1 && c->nheads <= 64, "vis: nheads=%d out of [1,64]", c->nheads);
+    SQ_REQUIRE(c->num_outputs >= 1, "vis: num_outputs=%d", c->num_outputs);
+    SQ_REQUIRE(c->num_clusters >= 1, "vis: num_clusters=%d", c->num_clusters);
+    return SQ_OK;
+}
+
+extern "C" int sq_vis_layout_init(const sq_vis_config* c, sq_vis_layout* out) {
+    if (int e = check_cfg(c)) return e;
+    SQ_REQUIRE(out != nullptr, "vis: null layout");
+    const int64_t D = c->input_dim, H = c->nheads, HD = H * SQ_HEAD_DIM, G = c->num_outputs;
+    int64_t off = 0;
+    auto take = [&](int64_t n) { off = (off + 7) / 8 * 8; const int64_t o = off; off += n; return o; };
+    out->pos = take((int64_t)c->num_clusters * D);
+    for (int l = 0; l < SQ_MAX_DEPTH; ++l) {
+        sq_vis_layer_offsets& L = out->layer[l];
+        if (l >= c->depth) { L = sq_vis_layer_offsets{-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1}; continue; }
+        L.f_w = take(HD * D);  L.f_b = take(HD);
+        L.s_w = take(HD * D);  L.s_b = take(HD);
+        L.lnf_g = take(HD);    L.lnf_b = take(HD);
+        L.lns_g = take(HD);    L.lns_b = take(HD);
+        L.c_w = take(HD * 2 * SQ_HEAD_DIM);  L.c_b = take(HD);
+        L.proj_w = take(D * HD);  L.proj_b = take(D);
+        L.ffln_g = take(D);    L.ffln_b = take(D);
+        L.ff1_w = take(D * D); L.ff1_b = take(D);
+        L.ff2_w = take(D * D); L.ff2_b = take(D);
+    }
+    out->head_ln_g = take(D);
+    out->head_ln_b = take(D);
+    out->head_w = take(G * D);
+    out->head_b = take(G);
+    out->total = (off + 7) / 8 * 8;
+    return SQ_OK;
+}
+
+extern "C" size_t sq_vis_workspace_bytes(const sq_vis_config* c, int dtype, int batch, int save_for_backward) {
+    if (check_cfg(c) != SQ_OK || batch < 1) return 0;
+    VisBufs b;
+    sq_vis_bufs(*c, dtype, batch, save_for_backward, nullptr, &b);
+    return b.bytes;
+}
+
+namespace {
+
+struct Lin {      // one nn.Linear on the flat parameter buffer
+    const void* w; int ldw; size_t w_bytes; const float* b;
+};
+
+}  // namespace
+
+extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* params, const void* params_lp, const float* x,
+                              float* out, int B, int save, void* workspace, size_t workspace_bytes, sq_stream_t stream_) {
+    if (int e = check_cfg(c)) return e;
+    hipStream_t st = (hipStream_t)stream_;
+    SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16, "vis_forward: dtype %d", dtype);
+    SQ_REQUIRE(params && x && out && workspace, "vis_forward: null pointer");
+    SQ_REQUIRE(dtype == SQ_F32 || params_lp, "vis_forward: bf16 mode needs the bf16 parameter shadow");
+    SQ_REQUIRE(B >= 1, "vis_forward: batch=%d", B);
+    sq_vis_layout lay;
+    if (int e = sq_vis_layout_init(c, &lay)) return e;
+    VisBufs w;
+    sq_vis_bufs(*c, dtype, B, save, (char*)workspace, &w);
+    if (w.bytes > workspace_bytes) {
+        sq_set_error("vis_forward: workspace %zu < required %zu", workspace_bytes, w.bytes);
+        return SQ_ERR_WORKSPACE;
+    }
+    const int N = c->num_clusters, D = c->input_dim, H = c->nheads, HD = H * SQ_HEAD_DIM, G = c->num_outputs;
+    const int M = B * N;
+    const size_t es = sq_dtype_size(dtype);
+    const bool lp = dtype == SQ_BF16;
+    const char* wbase = lp ? (const char*)params_lp : (const char*)params;
+    auto W = [&](int64_t off) { return (const void*)(wbase + (size_t)off * es); };
+    auto Wrem = [&](int64_t off) { return (size_t)(lay.total - off) * es; };
+    auto Pf = [&](int64_t off) { return params + off; };
+
+    if (int e = sq_k_add_pos(x, Pf(lay.pos), w.Xin[0], lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
+
+    for (int l = 0; l < c->depth; ++l) {
+        const sq_vis_layer_offsets& L = lay.layer[l];
+        const int s = save ? l : 0;
+        float* Xin = w.Xin[s];
+        const void* Xin_t = w.Xin_lp[s];
+        float* Xout = w.Xin[save ? l + 1 : 0];
+        void* Xout_lp = w.Xin_lp[save ? l + 1 : 0];
+
+        if (int e = sq_k_token_mean(Xin, w.Xbar32[s], lp ? (bf16_t*)w.Xbar[s] : nullptr, B, N, D, st)) return e;
+        {   // F = X Wf^T + bf
+            GemmArgs g; g.A = Xin_t; g.lda = D; g.a_bytes = (size_t)M * D * es;
+            g.B = W(L.f_w); g.ldb = D; g.b_bytes = Wrem(L.f_w); g.bias = Pf(L.f_b);
+            g.C = w.F[s]; g.ldc = HD; g.M = M; g.N = HD; g.K = D;
+            if (int e = sq_launch_gemm(g, dtype, st)) return e;
+        }
+        if (int e = sq_k_ln64_gelu(w.F[s], Pf(L.lnf_g), Pf(L.lnf_b), w.Lf[s], dtype, M, HD, st)) return e;
+        {   // Sm = Xbar Ws^T + bs
+            GemmArgs g; g.A = w.Xbar[s]; g.lda = D; g.a_bytes = (size_t)B * D * es;
+            g.B = W(L.s_w); g.ldb = D; g.b_bytes = Wrem(L.s_w); g.bias = Pf(L.s_b);
+            g.C = w.Sm[s]; g.ldc = HD; g.M = B; g.N = HD; g.K = D;
+            if (int e = sq_launch_gemm(g, dtype, st)) return e;
+        }
+        if (int e = sq_k_ln64_gelu(w.Sm[s], Pf(L.lns_g), Pf(L.lns_b), w.Ts[s], dtype, B, HD, st)) return e;
+        {   // Cs[b, h] = Ts[b, h] . Wc_h[:, 64:128]^T + bc_h     (cat order: [local, summary], tformer_lin.py:24)
+            GemmArgs g; g.A = w.Ts[s]; g.lda = HD; g.a_bytes = (size_t)B * HD * es; g.sA = SQ_HEAD_DIM;
+            g.B = W(L.c_w + SQ_HEAD_DIM); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w + SQ_HEAD_DIM); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
+            g.bias = Pf(L.c_b); g.sBias = SQ_HEAD_DIM;
+            g.C = w.Cs[s]; g.ldc = HD; g.sC = SQ_HEAD_DIM; g.M = B; g.N = SQ_HEAD_DIM; g.K = SQ_HEAD_DIM; g.batch = H;
+            if (int e = sq_launch_gemm(g, dtype, st)) return e;
+        }
+        {   // O[m, h] = GELU(Lf[m, h] . Wc_h[:, 0:64]^T + Cs[slide(m), h])
+            GemmArgs g; g.A = w.Lf[s]; g.lda = HD; g.a_bytes = (size_t)M * HD * es; g.sA = SQ_HEAD_DIM;
+            g.B = W(L.c_w); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
+            g.rowbias = w.Cs[s]; g.ldrb = HD; g.sRb = SQ_HEAD_DIM; g.rows_per_group = N;
+            g.act = SQ_ACT_GELU; g.Cpre = w.P[s]; g.ldpre = HD; g.sPre = SQ_HEAD_DIM;
+            g.C = w.O[s]; g.out_dtype = dtype; g.ldc = HD; g.sC = SQ_HEAD_DIM;
+            g.M = M; g.N = SQ_HEAD_DIM; g.K = SQ_HEAD_DIM; g.batch = H;
+            if (int e = sq_launch_gemm(g, dtype, st)) return e;
+        }
+        {   // X1 = O Wp^T + bp + X
+            GemmArgs g; g.A = w.O[s]; g.lda = HD; g.a_bytes = (size_t)M * HD * es;
+            g.B = W(L.proj_w); g.ldb = HD; g.b_bytes = Wrem(L.proj_w); g.bias = Pf(L.proj_b);
+            g.res = Xin; g.ldres = D; g.C = w.X1[s]; g.ldc = D; g.M = M; g.N = D; g.K = HD;
+            if (int e = sq_launch_gemm(g, dtype, st)) return e;
+        }
+        if (int e = sq_k_ln_rows(w.X1[s], Pf(L.ffln_g), Pf(L.ffln_b), w.Y[s], dtype, M, D, nullptr, nullptr, st)) return e;
+        {   // H1 = GELU(Y W1^T + b1)
+            GemmArgs g; g.A = w.Y[s]; g.lda = D; g.a_bytes = (size_t)M * D * es;
+            g.B = W(L.ff1_w); g.ldb = D; g.b_bytes = Wrem(L.ff1_w); g.bias = Pf(L.ff1_b);
+            g.act = SQ_ACT_GELU; g.Cpre = w.U[s]; g.ldpre = D;
+            g.C = w.H1[s]; g.out_dtype = dtype; g.ldc = D; g.M = M; g.N = D; g.K = D;
+            if (int e = sq_launch_gemm(g, dtype, st)) return e;
+        }
+        {   // X = H1 W2^T + b2 + X1
+            GemmArgs g; g.A = w.H1[s]; g.lda = D; g.a_bytes = (size_t)M * D * es;
+            g.B = W(L.ff2_w); g.ldb = D; g.b_bytes = Wrem(L.ff2_w); g.bias = Pf(L.ff2_b);
+            g.res = w.X1[s]; g.ldres = D; g.C = Xout; g.ldc = D;
+            g.C2 = lp ? (bf16_t*)Xout_lp : nullptr; g.ldc2 = D; g.M = M; g.N = D; g.K = D;
+            if (int e = sq_launch_gemm(g, dtype, st)) return e;
+        }
+    }
+    const float* Xfin = w.Xin[save ? c->depth : 0];
+    if (int e = sq_k_token_mean(Xfin, w.xm, nullptr, B, N, D, st)) return e;
+    if (int e = sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), w.xn, dtype, B, D, nullptr, nullptr, st)) return e;
+    {   // out = xn Wh^T + bh
+        GemmArgs g; g.A = w.xn; g.lda = D; g.a_bytes = (size_t)B * D * es;
+        g.B = W(lay.head_w); g.ldb = D; g.b_bytes = Wrem(lay.head_w); g.bias = Pf(lay.head_b);
+        g.C = out; g.ldc = G; g.M = B; g.N = G; g.K = D;
+        if (int e = sq_launch_gemm(g, dtype, st)) return e;
+    }
+    return SQ_OK;
+}
+
+extern "C" int sq_cast_f32_to_bf16(const float* src, void* dst, size_t n, sq_stream_t stream) {
+    SQ_REQUIRE(src && dst, "cast: null pointer");
+    return sq_k_f32_to_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream);
+}
+
+extern "C" int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual,
+                         int ldres, int act, void* C, int out_dtype, int ldc, int M, int N, int K, sq_stream_t stream) {
+    SQ_REQUIRE(A && W && C, "linear: null pointer");
+    SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16, "linear: dtype %d", dtype);
+    GemmArgs g;
+    const size_t es = sq_dtype_size(dtype);
+    g.A = A; g.lda = lda; g.a_bytes = ((size_t)(M - 1) * lda + K) * es;
+    g.B = W; g.ldb = ldw; g.b_bytes = ((size_t)(N - 1) * ldw + K) * es;
+    g.bias = bias; g.res = residual; g.ldres = ldres; g.act = act;
+    g.C = C; g.out_dtype = out_dtype; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    return sq_launch_gemm(g, dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,57 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports every symbol that
+include/sequoia_hip.h declares; host-side layout logic; no compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from sequoia_pub_amd import _lib
+from sequoia_pub_amd.vis import ViS, tensor_map, vis_layout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "sequoia_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 6
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sequoia_hip.h but not exported"
+
+
+def test_layout_is_aligned_and_dense():
+    cfg = _lib.VisConfig(1024, 6, 16, 20820, 100)
+    lay = vis_layout(cfg)
+    tm = tensor_map(cfg, lay)
+    assert len(tm) == 1013                                    # 1013 tensors at full size
+    n = sum(int(torch.tensor(s).prod()) for _, s in tm.values())
+    assert n == 53_758_292 or n > 53_000_000
+    spans = sorted((off, off + int(torch.tensor(s).prod())) for off, s in tm.values())
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0                                       # no overlap
+    assert lay.total >= spans[-1][1] and lay.total % 8 == 0
+    for f in ("f_w", "s_w", "c_w", "proj_w", "ff1_w", "ff2_w"):
+        assert getattr(lay.layer[0], f) % 8 == 0              # 16-byte aligned in bf16 as well
+
+
+def test_bad_config_reports_error():
+    cfg = _lib.VisConfig(100, 6, 16, 10, 100)                 # D not a multiple of 64
+    lay = _lib.VisLayout()
+    rc = _lib.lib().sq_vis_layout_init(ctypes.byref(cfg), ctypes.byref(lay))
+    assert rc != 0 and b"input_dim" in _lib.lib().sq_last_error()
+
+
+def test_model_without_gpu_raises_not_falls_back():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = ViS(8, 64, 1, 1, 64, 64, 64, device="cpu")
+    with pytest.raises(_lib.SequoiaHipError):
+        m(torch.zeros(1, 100, 64))

@@ -1,0 +1,82 @@
+"""sq_linear (MFMA NT GEMM engine) vs torch fp32/fp64 on the host: asymmetric operands,
+ragged M/N/K tails, bias / residual / activation epilogues, both MFMA paths."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import rel_err, to_bf16_f32
+
+pytestmark = pytest.mark.gpu
+
+from sequoia_pub_amd import _lib  # noqa: E402
+
+SHAPES = [(128, 128, 64), (200, 136, 96), (64, 20820 // 10, 128), (6400, 1024, 1024), (37, 64, 64),
+          (1000, 64, 256), (300, 520, 1032), (129, 65, 40)]
+
+
+def run_linear(dtype, A, W, bias, res, act, out_bf16=False):
+    dev = "cuda"
+    M, K = A.shape
+    N = W.shape[0]
+    tdt = torch.bfloat16 if dtype == _lib.SQ_BF16 else torch.float32
+    Ad, Wd = A.to(dev, tdt).contiguous(), W.to(dev, tdt).contiguous()
+    bd = bias.to(dev) if bias is not None else None
+    rd = res.to(dev) if res is not None else None
+    C = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _lib.check(_lib.lib().sq_linear(dtype, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(bd), _lib.ptr(rd), N, act,
+                                    _lib.ptr(C), _lib.SQ_BF16 if out_bf16 else _lib.SQ_F32, N, M, N, K,
+                                    _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return C.float().cpu()
+
+
+def ref_linear(A, W, bias, res, act):
+    y = A.double() @ W.double().T
+    if bias is not None:
+        y = y + bias.double()
+    if res is not None:
+        y = y + res.double()
+    if act == 1:
+        y = torch.nn.functional.gelu(y)
+    elif act == 2:
+        y = torch.relu(y)
+    return y
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_fp32_exact_mfma(M, N, K, act):
+    _lib.require_gpu()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + act)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1 + torch.arange(N)[:, None] * 1e-3     # asymmetric rows
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) if act != 1 else None
+    out = run_linear(_lib.SQ_F32, A, W, bias, res, act)
+    ref = ref_linear(A, W, bias, res, act)
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 2e-6, rel_err(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [s for s in SHAPES if s[2] % 8 == 0])
+def test_linear_bf16_mfma(M, N, K):
+    _lib.require_gpu()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = to_bf16_f32(torch.randn(M, K, generator=g))
+    W = to_bf16_f32(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g)
+    out = run_linear(_lib.SQ_BF16, A, W, bias, None, 0)
+    ref = ref_linear(A, W, bias, None, 0)          # operands already bf16-exact -> only fp32 accumulation differs
+    assert rel_err(out, ref) < 2e-6, rel_err(out, ref)
+    out16 = run_linear(_lib.SQ_BF16, A, W, bias, None, 2, out_bf16=True)
+    assert rel_err(out16, torch.relu(ref)) < 5e-3
+
+
+def test_bad_arguments_fail_loudly():
+    _lib.require_gpu()
+    A = torch.zeros(4, 6, device="cuda")
+    rc = _lib.lib().sq_linear(_lib.SQ_F32, _lib.ptr(A), 6, _lib.ptr(A), 6, None, None, 0, 0, _lib.ptr(A), 0, 4, 4, 4, 6,
+                              _lib.stream_ptr())
+    assert rc != 0 and b"multiple" in _lib.lib().sq_last_error()
