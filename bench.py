@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- slides/sec of the SEQUOIA hot path on MI355X (driver contract in the task brief).
+
+    python bench.py --gpus N --steps K --warmup W [--workload vis_train|vis_fwd|pipeline] [--dtype bf16|fp32]
+
+One process per GPU (torchrun / torch.distributed.run launches N of them); slides are
+independent units, so ranks shard them with no data-path collective.  Only the training
+workload has an exchange step: the RCCL all-reduce of the flat gradient buffer.
+
+Prints ONE JSON line on rank 0 with the headline value plus:
+  roofline     -- dominant kernel, algorithmic FLOP (or bytes) per launch / HIP-event duration,
+                  measured on the launch stream in extra instrumented steps after the timed region
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's torch-CPU path) timed on
+                  this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import sequoia_pub_amd  # noqa: E402,F401
+from sequoia_pub_amd import _lib, synth  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+VIS_CFG = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16,
+               dimensions_f=64, dimensions_s=64, dimensions_c=64)
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_region(step_fn, steps, warmup, world, device):
+    for _ in range(warmup):
+        step_fn()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def roofline_from_profile(step_fn, steps, dtype_name):
+    """Run `steps` more steps with HIP-event instrumentation on and pick the dominant kernel."""
+    _lib.prof_enable(True)
+    for _ in range(steps):
+        step_fn()
+    recs = _lib.prof_report()
+    _lib.prof_enable(False)
+    if not recs:
+        return None, []
+    dom = max(recs, key=lambda r: r["total_ms"])
+    avg_s = dom["total_ms"] / dom["count"] * 1e-3
+    total_ms = sum(r["total_ms"] for r in recs)
+    flops_per_byte = dom["flops"] / max(dom["bytes"], 1.0)
+    ridge = PEAK[dtype_name] * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if flops_per_byte >= ridge:
+        ach = dom["flops"] / avg_s / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s",
+                "frac": round(ach / PEAK[dtype_name], 4)}
+    else:
+        ach = dom["bytes"] / avg_s / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4)}
+    roof.update({"traffic": None, "kernel": dom["name"], "avg_us": round(avg_s * 1e6, 2),
+                 "launches_per_step": dom["count"] // max(steps, 1),
+                 "share_of_instrumented_time": round(dom["total_ms"] / total_ms, 3)})
+    return roof, recs
+
+
+# ------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------
+def make_vis(dtype_name, device):
+    from sequoia_pub_amd.vis import ViS
+    torch.manual_seed(99)
+    model = ViS(**VIS_CFG, num_clusters=100, device=str(device), compute_dtype=dtype_name)
+    model.to(device)
+    return model
+
+
+def workload_vis_fwd(args, rank, world, device):
+    """ViS forward on pre-computed cluster tokens (BASELINE config 2 model/shape, inference)."""
+    B = args.batch
+    model = make_vis(args.dtype, device).eval()
+    x = torch.from_numpy(synth.cluster_tokens(99 + rank, B, 1024)).to(device)
+
+    def step():
+        with torch.no_grad():
+            model(x)
+
+    def cpu_baseline():
+        from oracle import vis_oracle
+        sd = {k: v.cpu() for k, v in model.state_dict().items()}
+        nb = 8
+        xc = x[:nb].cpu()
+        torch.set_num_threads(os.cpu_count())
+        with torch.no_grad():
+            vis_oracle.vis_forward(sd, xc)
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 10.0:
+                vis_oracle.vis_forward(sd, xc)
+                reps += 1
+            dt = time.perf_counter() - t0
+        return {"value": round(nb * reps / dt, 3), "unit": "slides/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"oracle.vis_oracle.vis_forward (torch-CPU fp32), {reps} x batch {nb} of the same tokens"}
+
+    return dict(step=step, slides_per_step=B, cpu_baseline=cpu_baseline,
+                config={"workload": "vis_fwd: ViS(D=1024, depth 6, 16 heads, G=20820) forward on 100 cluster tokens/slide",
+                        "batch_per_gpu": B, "parallelism": f"slide-sharded x{world}"})
+
+
+def workload_vis_train(args, rank, world, device):
+    """BASELINE config 2: lin-attn (ViS) forward + backward + AdamW, 20k genes, batch 64 slides per GPU."""
+    from sequoia_pub_amd import train as sq_train
+    B = args.batch
+    model = make_vis(args.dtype, device).train()
+    x = torch.from_numpy(synth.cluster_tokens(99 + rank, B, 1024)).to(device)
+    y = torch.from_numpy(synth.rna_targets(199 + rank, B, VIS_CFG["num_outputs"])).to(device)
+    stepper = sq_train.FusedTrainStep(model, lr=1e-3, world_size=world)
+
+    def step():
+        stepper.step(x, y)
+
+    def cpu_baseline():
+        from oracle import vis_oracle
+        sd = {k: v.cpu() for k, v in model.state_dict().items()}
+        nb = 8
+        xc, yc = x[:nb].cpu(), y[:nb].cpu()
+        m = {k: torch.zeros_like(v) for k, v in sd.items()}
+        v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+        torch.set_num_threads(os.cpu_count())
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 2 or time.perf_counter() - t0 < 12.0:
+            _, _, grads = vis_oracle.vis_loss_and_grads(sd, xc, yc)
+            vis_oracle.adamw_step(sd, grads, m, v2, reps + 1)
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": round(nb * reps / dt, 3), "unit": "slides/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"oracle ViS fwd+bwd+AdamW (torch-CPU fp32 autograd), {reps} steps x batch {nb}"}
+
+    return dict(step=step, slides_per_step=B, cpu_baseline=cpu_baseline,
+                config={"workload": "vis_train: ViS(D=1024 UNI-dim, depth 6, 16 heads, G=20820) fwd+bwd+AdamW on "
+                                    "100 cluster tokens/slide (BASELINE config 2)",
+                        "batch_per_gpu": B, "global_batch": B * world,
+                        "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient)" if world > 1 else "")})
+
+
+WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "vis_fwd"), choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=64, help="slides per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = dist_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    _lib.require_gpu()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    wl = WORKLOADS[args.workload](args, rank, world, device)
+    dt = timed_region(wl["step"], args.steps, args.warmup, world, device)
+    slides = wl["slides_per_step"] * world * args.steps
+    value = slides / dt
+
+    roof, recs = roofline_from_profile(wl["step"], min(args.steps, 5), args.dtype)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = wl["cpu_baseline"]()
+
+    if rank == 0:
+        line = {"metric": "slides/sec (1000-patch WSI, UNI-dim, 20k-gene head)", "value": round(value, 3),
+                "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": wl["config"],
+                "roofline": roof, "cpu_baseline": cpu}
+        if os.environ.get("SQ_BENCH_KERNELS"):
+            with open(os.environ["SQ_BENCH_KERNELS"], "w") as f:
+                json.dump(sorted(recs, key=lambda r: -r["total_ms"]), f, indent=1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,13 @@ int sq_version(void);
 /* 1 when a gfx950 device is visible to the HIP runtime, else 0 (never fails) */
 int sq_device_ok(void);
 
+/* HIP-event timing of the library's own launches (bench.py roofline leg; no reference
+ * counterpart).  sq_prof_enable(1) makes every instrumented launch record two events on
+ * its stream; sq_prof_report writes a JSON array of {name,count,total_ms,flops,bytes}
+ * (flops/bytes = algorithmic work per launch) into buf and clears the records. */
+int sq_prof_enable(int on);
+int sq_prof_report(char* buf, size_t cap);
+
 /* ------------------------------------------------------------------------------
  * ViS aggregator  (src/tformer_lin.py:80-106 ViS; :64-77 SummaryTransformer;
  * :29-48 MultiHeadSummary; :7-26 SummaryMixing; :51-61 FeedForward)
@@ -80,6 +87,35 @@ size_t sq_vis_workspace_bytes(const sq_vis_config* cfg, int dtype, int batch, in
 int sq_vis_forward(const sq_vis_config* cfg, int dtype, const float* params, const void* params_lp, const float* x,
                    float* out, int batch, int save_for_backward, void* workspace, size_t workspace_bytes,
                    sq_stream_t stream);
+
+/* Backward of ViS.forward -- replaces torch autograd over tformer_lin.py in the training loop
+ * (src/vit.py:163-180 `loss.backward()`).  grad_out f32 [B, G]; grad_params: flat f32 buffer with
+ * the parameter layout, fully overwritten; grad_x f32 [B, num_clusters, D] or NULL.
+ * fwd_workspace must be the workspace of the matching sq_vis_forward(save_for_backward = 1). */
+size_t sq_vis_backward_workspace_bytes(const sq_vis_config* cfg, int dtype, int batch);
+int sq_vis_backward(const sq_vis_config* cfg, int dtype, const float* params, const void* params_lp,
+                    const float* grad_out, float* grad_params, float* grad_x, int batch, void* fwd_workspace,
+                    size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, sq_stream_t stream);
+
+/* ------------------------------------------------------------------------------
+ * Training-step pieces of src/vit.py:117-243 `train`
+ * ---------------------------------------------------------------------------- */
+size_t sq_train_scratch_bytes(int num_outputs);
+/* nn.MSELoss() (vit.py:129,166): *loss_out = mean((pred-target)^2) over n elements (device scalar);
+ * grad[i] = grad_scale * (pred[i]-target[i])  (grad_scale = 2/n for the plain loss; grad may be NULL). */
+int sq_mse_loss_grad(const float* pred, const float* target, size_t n, float grad_scale, float* grad, float* loss_out,
+                     void* scratch, sq_stream_t stream);
+/* torch.optim.AdamW(lr, amsgrad=False, weight_decay) (src/main.py:180-183) on a flat fp32 buffer;
+ * step is the 1-based step count; grads are multiplied by grad_scale first (1/world for an
+ * all-reduced sum); params_lp (bf16 shadow) is refreshed in the same pass when not NULL. */
+int sq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* params_lp, size_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  sq_stream_t stream);
+/* Per-batch metrics the reference computes on the host every batch (vit.py:167-168):
+ * out3[0] = sklearn mean_absolute_error, out3[1] = compute_correlations (src/he2rna.py:140-149:
+ * mean per-gene Pearson r over genes with a non-constant target, NaN r dropped), out3[2] = #genes used. */
+int sq_batch_metrics(const float* pred, const float* target, int batch, int num_outputs, float* out3, void* scratch,
+                     sq_stream_t stream);
 
 /* dst_bf16[i] = bf16(src[i]) -- refresh of the bf16 parameter shadow after an optimizer step */
 int sq_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, sq_stream_t stream);

@@ -59,6 +59,23 @@ def _declare(lib):
     lib.sq_vis_workspace_bytes.argtypes = [ctypes.POINTER(VisConfig), i32, i32, i32]
     lib.sq_vis_forward.restype = i32
     lib.sq_vis_forward.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, i32, i32, vp, sz, vp]
+    lib.sq_vis_backward_workspace_bytes.restype = sz
+    lib.sq_vis_backward_workspace_bytes.argtypes = [ctypes.POINTER(VisConfig), i32, i32]
+    lib.sq_vis_backward.restype = i32
+    lib.sq_vis_backward.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, vp, i32, vp, sz, vp, sz, vp]
+    lib.sq_train_scratch_bytes.restype = sz
+    lib.sq_train_scratch_bytes.argtypes = [i32]
+    f32 = ctypes.c_float
+    lib.sq_mse_loss_grad.restype = i32
+    lib.sq_mse_loss_grad.argtypes = [vp, vp, sz, f32, vp, vp, vp, vp]
+    lib.sq_adamw_step.restype = i32
+    lib.sq_adamw_step.argtypes = [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, f32, vp]
+    lib.sq_batch_metrics.restype = i32
+    lib.sq_batch_metrics.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.sq_prof_enable.restype = i32
+    lib.sq_prof_enable.argtypes = [i32]
+    lib.sq_prof_report.restype = i32
+    lib.sq_prof_report.argtypes = [ctypes.c_char_p, sz]
     lib.sq_linear.restype = i32
     lib.sq_linear.argtypes = [i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]
     lib.sq_cast_f32_to_bf16.restype = i32
@@ -114,3 +131,16 @@ def stream_ptr(device=None):
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def prof_enable(on):
+    check(lib().sq_prof_enable(int(bool(on))))
+
+
+def prof_report():
+    """Per-kernel HIP-event timings recorded since prof_enable(True) (synchronises first)."""
+    import json
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 20)
+    check(lib().sq_prof_report(buf, len(buf)))
+    return json.loads(buf.value.decode())

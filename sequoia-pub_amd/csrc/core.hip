@@ -28,3 +28,82 @@ extern "C" int sq_device_ok(void) {
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
+
+// ------------------------------------------------------------------------------------
+// HIP-event kernel timing, used by bench.py's roofline leg: every instrumented launch is
+// bracketed by two events on the launch stream; sq_prof_report aggregates by kernel name.
+// Off by default (no events are recorded in the timed region of the headline number).
+// ------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+struct ProfRec { hipEvent_t a, b; std::string name; double flops, bytes; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+bool sq_prof_on() { return g_prof_on; }
+
+int sq_prof_begin(const char* name, double flops, double bytes, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return -1;
+    ProfRec r{get_event(), get_event(), name, flops, bytes};
+    if (!r.a || !r.b) return -1;
+    hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+    return (int)g_recs.size() - 1;
+}
+
+void sq_prof_end(int idx, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx < 0 || idx >= (int)g_recs.size()) return;
+    hipEventRecord(g_recs[idx].b, st);
+}
+
+extern "C" int sq_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return SQ_OK;
+}
+
+// Writes a JSON array [{"name":..,"count":..,"total_ms":..,"flops":..,"bytes":..}, ...] (flops/bytes per launch)
+// into buf, clears the records.  The caller synchronises the stream(s) first.
+extern "C" int sq_prof_report(char* buf, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    struct Agg { long count = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            Agg& a = agg[r.name];
+            a.count++; a.ms += ms; a.flops = r.flops; a.bytes = r.bytes;
+        }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    std::string s = "[";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[384];
+        snprintf(line, sizeof(line), "%s{\"name\":\"%s\",\"count\":%ld,\"total_ms\":%.6f,\"flops\":%.1f,\"bytes\":%.1f}",
+                 first ? "" : ",", kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.flops, kv.second.bytes);
+        s += line;
+        first = false;
+    }
+    s += "]";
+    SQ_REQUIRE(buf && s.size() + 1 <= cap, "prof_report: buffer of %zu bytes too small (%zu needed)", cap, s.size() + 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return SQ_OK;
+}

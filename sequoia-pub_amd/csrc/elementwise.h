@@ -14,5 +14,27 @@ int sq_k_ln64_gelu(const float* x, const float* g, const float* b, void* y, int 
 // dst = (T) src
 int sq_k_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
 int sq_k_bf16_to_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s);
-// dst[c][r] = src[r][c]  (2-byte or 4-byte elements), batched
-int sq_k_transpose(const void* src, void* dst, int R, int C, int elem_size, int batch, hipStream_t s);
+// dst[c][r] = src[r][c] for r < R, 0 for R <= r < ldd  (2- or 4-byte elements; src leading dim lds, dst ldd >= R);
+// batched with element strides.  The zero padding lets ragged R feed the GEMM's 16-byte K chunks.
+int sq_k_transpose(const void* src, int lds_, void* dst, int ldd, int R, int C, int elem_size, int batch,
+                   long long sstride, long long dstride, hipStream_t s);
+// dst[r][0:C] = (T) src[r][0:C], dst[r][C:ldd] = 0
+int sq_k_cast_pad(const float* src, int lds_, void* dst, int dst_dtype, int ldd, int R, int C, hipStream_t s);
+
+// ---- backward helpers -------------------------------------------------------------------------
+// out[c] = sum_r x[r, c]   (x f32 or bf16, leading dim ld); ws: >= colsum_ws_floats(C) floats
+size_t sq_colsum_ws_floats(int C);
+int sq_k_colsum(const void* x, int dtype, int R, int C, int ld, float* ws, float* out, hipStream_t s);
+// out[g, c] = scale * sum_{n<N} x[g*N + n, c]     (x f32 or bf16 [G*N, C])
+int sq_k_group_sum(const void* x, int dtype, int G, int N, int C, float scale, float* out, hipStream_t s);
+// dst[b, n, :] = scale * src[b, :]; optional bf16 copy
+int sq_k_bcast_rows(const float* src, float scale, float* dst, bf16_t* dst_lp, int B, int N, int D, hipStream_t s);
+// out[n, :] = sum_b x[b, n, :]
+int sq_k_batch_sum(const float* x, float* out, int B, int ND, hipStream_t s);
+// LayerNorm_D backward: dx = dres + dLN(dy; x, g);  dg/db = column sums.  ws >= ln_bwd_ws_floats(D) floats
+size_t sq_ln_bwd_ws_floats(int D);
+int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const float* dres, float* dx, bf16_t* dx_lp,
+                     float* dg, float* db, float* ws, int R, int D, hipStream_t s);
+// backward of y = GELU(LN64(x)*g + b): dx (f32 or bf16 by out_dtype), dg/db [C].  ws >= ln_bwd_ws_floats(C)
+int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const float* b, void* dx, int out_dtype,
+                       float* dg, float* db, float* ws, int R, int C, hipStream_t s);

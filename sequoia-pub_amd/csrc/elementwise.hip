@@ -132,21 +132,33 @@ __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __rest
         dst[i] = bf16_to_f32(src[i]);
 }
 
-// 64x64 tile through LDS (+1 padding), coalesced on both sides
+// 64x64 tile through LDS (+1 padding), coalesced on both sides; zero-fills dst columns [R, ldd)
 template <typename E>
-__global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ src, E* __restrict__ dst, int R, int C) {
+__global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ src, int lds_, E* __restrict__ dst, int ldd,
+                                                        int R, int C, long long sstride, long long dstride) {
     __shared__ E tile[64][65];
-    const size_t boff = (size_t)blockIdx.z * R * C;
+    src += (long long)blockIdx.z * sstride;
+    dst += (long long)blockIdx.z * dstride;
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
-        if (r < R && c < C) tile[i][tx] = src[boff + (size_t)r * C + c];
+        tile[i][tx] = (r < R && c < C) ? src[(size_t)r * lds_ + c] : (E)0;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
         const int c = c0 + i, r = r0 + tx;
-        if (r < R && c < C) dst[boff + (size_t)c * R + r] = tile[tx][i];
+        if (r < ldd && c < C) dst[(size_t)c * ldd + r] = tile[tx][i];
+    }
+}
+
+__global__ void cast_pad_kernel(const float* __restrict__ src, int lds_, void* __restrict__ dst, int out_bf16, int ldd, int R, int C) {
+    const size_t total = (size_t)R * ldd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ldd), c = (int)(i - (size_t)r * ldd);
+        const float v = c < C ? src[(size_t)r * lds_ + c] : 0.f;
+        if (out_bf16) reinterpret_cast<bf16_t*>(dst)[i] = f32_to_bf16(v);
+        else reinterpret_cast<float*>(dst)[i] = v;
     }
 }
 
@@ -213,11 +225,23 @@ int sq_k_bf16_to_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s) {
     return SQ_OK;
 }
 
-int sq_k_transpose(const void* src, void* dst, int R, int C, int elem_size, int batch, hipStream_t s) {
-    const dim3 grid((C + 63) / 64, (R + 63) / 64, batch), block(256);
-    if (elem_size == 2) hipLaunchKernelGGL(transpose_kernel<uint16_t>, grid, block, 0, s, (const uint16_t*)src, (uint16_t*)dst, R, C);
-    else if (elem_size == 4) hipLaunchKernelGGL(transpose_kernel<uint32_t>, grid, block, 0, s, (const uint32_t*)src, (uint32_t*)dst, R, C);
+int sq_k_transpose(const void* src, int lds_, void* dst, int ldd, int R, int C, int elem_size, int batch,
+                   long long sstride, long long dstride, hipStream_t s) {
+    SQ_REQUIRE(ldd >= R && lds_ >= C, "transpose: ldd=%d < R=%d or lds=%d < C=%d", ldd, R, lds_, C);
+    const dim3 grid((C + 63) / 64, (ldd + 63) / 64, batch), block(256);
+    if (elem_size == 2)
+        hipLaunchKernelGGL(transpose_kernel<uint16_t>, grid, block, 0, s, (const uint16_t*)src, lds_, (uint16_t*)dst, ldd, R, C, sstride, dstride);
+    else if (elem_size == 4)
+        hipLaunchKernelGGL(transpose_kernel<uint32_t>, grid, block, 0, s, (const uint32_t*)src, lds_, (uint32_t*)dst, ldd, R, C, sstride, dstride);
     else { sq_set_error("transpose: elem_size %d", elem_size); return SQ_ERR_ARG; }
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_cast_pad(const float* src, int lds_, void* dst, int dst_dtype, int ldd, int R, int C, hipStream_t s) {
+    SQ_REQUIRE(ldd >= C, "cast_pad: ldd=%d < C=%d", ldd, C);
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for((size_t)R * ldd, 256)), dim3(256), 0, s, src, lds_, dst,
+                       dst_dtype == SQ_BF16, ldd, R, C);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }

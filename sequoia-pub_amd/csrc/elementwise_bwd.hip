@@ -1,0 +1,298 @@
+// Backward-pass helper kernels (column reductions, LayerNorm / LN64+GELU gradients).
+// All reductions are two-stage with a fixed order, so gradients are run-to-run deterministic.
+#include "elementwise.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+constexpr int COLSUM_SPLITS = 64;
+constexpr int LN_BWD_PARTIALS = 1024;
+
+template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p, size_t i);
+template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_as_f32<bf16_t>(const bf16_t* p, size_t i) { return bf16_to_f32(p[i]); }
+
+// stage 1: block (64 columns x 4 row lanes) sums rows [r_lo, r_hi) of its column strip
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_stage1(const T* __restrict__ x, int R, int C, int ld, int rows_per_split,
+                                                     float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int r_lo = blockIdx.y * rows_per_split;
+    const int r_hi = min(R, r_lo + rows_per_split);
+    float acc = 0.f;
+    if (c < C)
+        for (int r = r_lo + ty; r < r_hi; r += 4) acc += ld_as_f32<T>(x, (size_t)r * ld + c);
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+__global__ void colsum_stage2(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += partial[(size_t)s * C + c];
+    out[c] = acc;
+}
+
+template <typename T>
+__global__ void group_sum_kernel(const T* __restrict__ x, int G, int N, int C, float scale, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += ld_as_f32<T>(x, ((size_t)g * N + n) * C + c);
+    out[i] = acc * scale;
+}
+
+__global__ void bcast_rows_kernel(const float4* __restrict__ src, float scale, float4* __restrict__ dst, uint2* __restrict__ dst_lp,
+                                  int N, int D4, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / ((size_t)N * D4);
+        const int d = (int)(i % D4);
+        float4 v = src[b * D4 + d];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        dst[i] = v;
+        if (dst_lp) dst_lp[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+}
+
+__global__ void batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int ND) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ND) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += x[(size_t)b * ND + i];
+    out[i] = acc;
+}
+
+// one wave per row (grid-strided); lane owns float4 columns i*64+lane; per-wave dg/db partials go to ws
+template <int MAXI>
+__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ g, const float* __restrict__ dres,
+                                                          float* __restrict__ dx, bf16_t* __restrict__ dx_lp,
+                                                          float* __restrict__ ws, int R, int D) {
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int D4 = D >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4 ag[MAXI], ab[MAXI], gg[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = i * 64 + lane;
+        gg[i] = c < D4 ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = wave_global; row < R; row += nwaves) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+        const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * D);
+        float4 xv[MAXI], dv[MAXI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = i * 64 + lane;
+            xv[i] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[i] = c < D4 ? dyr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = i * 64 + lane;
+            if (c < D4) {
+                xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+                q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + LN_EPS);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            // xhat, dxhat = dy * gamma; accumulate parameter grads
+            xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;
+            ag[i].x += dv[i].x * xv[i].x; ag[i].y += dv[i].y * xv[i].y; ag[i].z += dv[i].z * xv[i].z; ag[i].w += dv[i].w * xv[i].w;
+            ab[i].x += dv[i].x; ab[i].y += dv[i].y; ab[i].z += dv[i].z; ab[i].w += dv[i].w;
+            dv[i].x *= gg[i].x; dv[i].y *= gg[i].y; dv[i].z *= gg[i].z; dv[i].w *= gg[i].w;
+            c1 += (dv[i].x + dv[i].y) + (dv[i].z + dv[i].w);
+            c2 += (dv[i].x * xv[i].x + dv[i].y * xv[i].y) + (dv[i].z * xv[i].z + dv[i].w * xv[i].w);
+        }
+        c1 = wave_sum(c1) / (float)D;
+        c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c = i * 64 + lane;
+            if (c < D4) {
+                float4 o;
+                o.x = rstd * (dv[i].x - c1 - xv[i].x * c2);
+                o.y = rstd * (dv[i].y - c1 - xv[i].y * c2);
+                o.z = rstd * (dv[i].z - c1 - xv[i].z * c2);
+                o.w = rstd * (dv[i].w - c1 - xv[i].w * c2);
+                if (dres) {
+                    const float4 r4 = reinterpret_cast<const float4*>(dres + (size_t)row * D)[c];
+                    o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+                }
+                reinterpret_cast<float4*>(dx + (size_t)row * D)[c] = o;
+                if (dx_lp) reinterpret_cast<uint2*>(dx_lp + (size_t)row * D)[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+            }
+        }
+    }
+    float4* wg = reinterpret_cast<float4*>(ws + (size_t)wave_global * 2 * D);
+    float4* wb = reinterpret_cast<float4*>(ws + (size_t)wave_global * 2 * D + D);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = i * 64 + lane;
+        if (c < D4) { wg[c] = ag[i]; wb[c] = ab[i]; }
+    }
+}
+
+// thread owns float4 column(s) (fixed), walks rows; 16 lanes = one 64-wide group
+template <int NCH>
+__global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ g, const float* __restrict__ b,
+                                                            void* __restrict__ dx, int out_bf16, float* __restrict__ ws,
+                                                            int R, int C) {
+    const int C16 = C >> 2;
+    const int cols_per_iter = NCH > 1 ? 256 : min(C16, 256);
+    const int rpi = 256 / cols_per_iter;                 // rows per block iteration
+    const int rsub = threadIdx.x / cols_per_iter;
+    const int col0 = threadIdx.x % cols_per_iter;
+    float4 ag[NCH], ab[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) ag[k] = ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int row = blockIdx.x * rpi + rsub; row < R; row += gridDim.x * rpi) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c4 = k * 256 + col0;
+            const float4 v = reinterpret_cast<const float4*>(x + (size_t)row * C)[c4];
+            const float4 d = reinterpret_cast<const float4*>(dy + (size_t)row * C)[c4];
+            const float4 gg = reinterpret_cast<const float4*>(g)[c4], bb = reinterpret_cast<const float4*>(b)[c4];
+            float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * (1.0f / 64.0f);
+            float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+            float q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
+            a0 *= rstd; a1 *= rstd; a2 *= rstd; a3 *= rstd;                       // xhat
+            const float z0 = d.x * gelu_erf_grad(a0 * gg.x + bb.x), z1 = d.y * gelu_erf_grad(a1 * gg.y + bb.y);
+            const float z2 = d.z * gelu_erf_grad(a2 * gg.z + bb.z), z3 = d.w * gelu_erf_grad(a3 * gg.w + bb.w);
+            ag[k].x += z0 * a0; ag[k].y += z1 * a1; ag[k].z += z2 * a2; ag[k].w += z3 * a3;
+            ab[k].x += z0; ab[k].y += z1; ab[k].z += z2; ab[k].w += z3;
+            const float h0 = z0 * gg.x, h1 = z1 * gg.y, h2 = z2 * gg.z, h3 = z3 * gg.w;   // d xhat
+            float c1 = (h0 + h1) + (h2 + h3);
+            float c2 = (h0 * a0 + h1 * a1) + (h2 * a2 + h3 * a3);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+            c1 *= (1.0f / 64.0f); c2 *= (1.0f / 64.0f);
+            float4 o4;
+            o4.x = rstd * (h0 - c1 - a0 * c2); o4.y = rstd * (h1 - c1 - a1 * c2);
+            o4.z = rstd * (h2 - c1 - a2 * c2); o4.w = rstd * (h3 - c1 - a3 * c2);
+            if (out_bf16) reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(dx) + (size_t)row * C)[c4] =
+                              make_uint2(pack_bf16x2(o4.x, o4.y), pack_bf16x2(o4.z, o4.w));
+            else reinterpret_cast<float4*>(reinterpret_cast<float*>(dx) + (size_t)row * C)[c4] = o4;
+        }
+    }
+    const size_t prow = (size_t)blockIdx.x * rpi + rsub;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c4 = k * 256 + col0;
+        reinterpret_cast<float4*>(ws + prow * 2 * C)[c4] = ag[k];
+        reinterpret_cast<float4*>(ws + prow * 2 * C + C)[c4] = ab[k];
+    }
+}
+
+int colsum_impl(const void* x, int dtype, int R, int C, int ld, float* ws, float* out, hipStream_t s) {
+    int nsplit = (R + 63) / 64;
+    if (nsplit > COLSUM_SPLITS) nsplit = COLSUM_SPLITS;
+    if (nsplit < 1) nsplit = 1;
+    const int rows_per_split = (R + nsplit - 1) / nsplit;
+    const dim3 grid((C + 63) / 64, nsplit), block(256);
+    if (dtype == SQ_BF16) hipLaunchKernelGGL(colsum_stage1<bf16_t>, grid, block, 0, s, (const bf16_t*)x, R, C, ld, rows_per_split, ws);
+    else hipLaunchKernelGGL(colsum_stage1<float>, grid, block, 0, s, (const float*)x, R, C, ld, rows_per_split, ws);
+    SQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, ws, nsplit, C, out);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+}  // namespace
+
+size_t sq_colsum_ws_floats(int C) { return (size_t)COLSUM_SPLITS * C; }
+
+int sq_k_colsum(const void* x, int dtype, int R, int C, int ld, float* ws, float* out, hipStream_t s) {
+    SQ_REQUIRE(R > 0 && C > 0 && ld >= C, "colsum: R=%d C=%d ld=%d", R, C, ld);
+    return colsum_impl(x, dtype, R, C, ld, ws, out, s);
+}
+
+int sq_k_group_sum(const void* x, int dtype, int G, int N, int C, float scale, float* out, hipStream_t s) {
+    const int total = G * C;
+    if (dtype == SQ_BF16) hipLaunchKernelGGL(group_sum_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)x, G, N, C, scale, out);
+    else hipLaunchKernelGGL(group_sum_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)x, G, N, C, scale, out);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_bcast_rows(const float* src, float scale, float* dst, bf16_t* dst_lp, int B, int N, int D, hipStream_t s) {
+    SQ_REQUIRE(D % 4 == 0, "bcast_rows: D=%d", D);
+    const size_t total4 = (size_t)B * N * D / 4;
+    size_t g = (total4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3((int)g), dim3(256), 0, s, (const float4*)src, scale, (float4*)dst, (uint2*)dst_lp, N, D / 4, total4);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_batch_sum(const float* x, float* out, int B, int ND, hipStream_t s) {
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((ND + 255) / 256), dim3(256), 0, s, x, out, B, ND);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+size_t sq_ln_bwd_ws_floats(int D) { return (size_t)LN_BWD_PARTIALS * 2 * D + sq_colsum_ws_floats(2 * D); }
+
+int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const float* dres, float* dx, bf16_t* dx_lp, float* dg,
+                     float* db, float* ws, int R, int D, hipStream_t s) {
+    SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows_bwd: D=%d", D);
+    int nblk = (R + 3) / 4;
+    if (nblk > LN_BWD_PARTIALS / 4) nblk = LN_BWD_PARTIALS / 4;
+    const dim3 grid(nblk), block(256);
+    if (D <= 1024) hipLaunchKernelGGL(ln_rows_bwd_kernel<4>, grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);
+    else if (D <= 2048) hipLaunchKernelGGL(ln_rows_bwd_kernel<8>, grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);
+    else hipLaunchKernelGGL(ln_rows_bwd_kernel<16>, grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);
+    SQ_LAUNCH_CHECK();
+    // partial rows are [dg | db] of length 2D: one column-sum over nblk*4 partial rows, then split
+    float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * D;
+    float* both = cs_ws + sq_colsum_ws_floats(2 * D) - 2 * D;     // tail of the colsum scratch is free: nsplit <= 16 here
+    if (int e = colsum_impl(ws, SQ_F32, nblk * 4, 2 * D, 2 * D, cs_ws, both, s)) return e;
+    SQ_HIP_CHECK(hipMemcpyAsync(dg, both, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+    SQ_HIP_CHECK(hipMemcpyAsync(db, both + D, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+    return SQ_OK;
+}
+
+int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const float* b, void* dx, int out_dtype, float* dg,
+                       float* db, float* ws, int R, int C, hipStream_t s) {
+    const int C16 = C / 4;
+    SQ_REQUIRE(C % 64 == 0 && ((C16 <= 256 && 256 % C16 == 0) || C16 == 512 || C16 == 1024),
+               "ln64_gelu_bwd: C=%d (nheads must be a power of two <= 64 for the training path)", C);
+    const int nch = C16 <= 256 ? 1 : C16 / 256;
+    const int rpi = C16 <= 256 ? 256 / C16 : 1;
+    int nblk = (R + rpi - 1) / rpi;
+    if (nblk * rpi > LN_BWD_PARTIALS) nblk = LN_BWD_PARTIALS / rpi;
+    const dim3 grid(nblk), block(256);
+    const int ob = out_dtype == SQ_BF16;
+    if (nch == 1) hipLaunchKernelGGL(ln64_gelu_bwd_kernel<1>, grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+    else if (nch == 2) hipLaunchKernelGGL(ln64_gelu_bwd_kernel<2>, grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+    else hipLaunchKernelGGL(ln64_gelu_bwd_kernel<4>, grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+    SQ_LAUNCH_CHECK();
+    float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * C;
+    float* both = cs_ws + sq_colsum_ws_floats(2 * C) - 2 * C;
+    if (int e = colsum_impl(ws, SQ_F32, nblk * rpi, 2 * C, 2 * C, cs_ws, both, s)) return e;
+    SQ_HIP_CHECK(hipMemcpyAsync(dg, both, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+    SQ_HIP_CHECK(hipMemcpyAsync(db, both + C, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+    return SQ_OK;
+}

@@ -1,4 +1,5 @@
-// MFMA "NT" GEMM engine of libsequoia_hip:  C[M,N] = act(A[M,K] . B[N,K]^T + bias + rowbias + res)
+// MFMA "NT" GEMM engine of libsequoia_hip:
+//   C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias + rowbias + res) * GELU'(gelu_grad_of)
 // Both operands are K-contiguous (activations row-major, nn.Linear / packed conv weights
 // [out, in]).  A can also be an implicit-GEMM view of an NHWC activation (conv taps).
 #pragma once
@@ -17,13 +18,15 @@ struct GemmArgs {
     const float* bias = nullptr;      // [N]
     const float* rowbias = nullptr;   // [ceil(M / rows_per_group), N] (ldrb)
     const void* res = nullptr;        // [M, N] (ldres) f32 or bf16 (res_dtype)
+    const float* gelu_grad_of = nullptr;  // [M, N] (ldgg): result *= GELU'(gelu_grad_of[m,n]) (backward of an activation)
+    float alpha = 1.0f;               // scales the accumulator before the epilogue terms
     int M = 0, N = 0, K = 0;
-    int lda = 0, ldb = 0, ldc = 0, ldc2 = 0, ldpre = 0, ldres = 0, ldrb = 0;
+    int lda = 0, ldb = 0, ldc = 0, ldc2 = 0, ldpre = 0, ldres = 0, ldrb = 0, ldgg = 0;
     int rows_per_group = 1;
     int act = SQ_ACT_NONE;
     int out_dtype = SQ_F32, res_dtype = SQ_F32;
     int batch = 1;
-    long long sA = 0, sB = 0, sC = 0, sC2 = 0, sPre = 0, sBias = 0, sRb = 0, sRes = 0;   // per-batch strides (elements)
+    long long sA = 0, sB = 0, sC = 0, sC2 = 0, sPre = 0, sBias = 0, sRb = 0, sRes = 0, sGg = 0;   // per-batch strides (elements)
     // implicit-GEMM convolution view of A: NHWC [n, H, W, Cin]; K = KH*KW*Cin, tap-major
     int conv = 0, H = 0, W = 0, Cin = 0, OH = 0, OW = 0, KW = 1, stride = 1, pad = 0;
     size_t a_bytes = 0, b_bytes = 0;   // extents of A and B for the buffer descriptors (< 2 GiB)

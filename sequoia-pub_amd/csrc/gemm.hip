@@ -11,6 +11,7 @@
 // fp32 path: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) -- the parity mode.
 // bf16 path: v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the perf mode.
 #include "gemm.h"
+#include <cstdio>
 
 namespace {
 
@@ -38,7 +39,7 @@ template <> struct Mma<bf16_t> {
     }
 };
 
-template <typename T, int WTM, int WTN>
+template <typename T, int WTM, int WTN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -76,65 +77,70 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     const int c16 = tid & 7;      // 16-B chunk inside the 128-B K-tile row
     const int r0 = tid >> 3;      // row inside a 32-row group
 
-    // per-thread row bookkeeping
-    uint32_t a_row_off[RA];       // element offset of the row start (plain) / pixel base (conv)
+    // per-thread row bookkeeping.  Plain GEMM: the byte offset of each row's chunk is loop-invariant
+    // (the K-tile offset travels in the scalar soffset operand), so the K loop issues its loads
+    // back-to-back with no address arithmetic.  Conv: one offset per (row, tap).
+    uint32_t a_off[RA], b_off[RB];      // byte offsets at k = 0 (OOB when the row is out of range)
     int a_ih0[RA], a_iw0[RA];
+    uint32_t a_pix[RA];
     bool a_ok[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
         const int m = m0 + r0 + 32 * j;
         a_ok[j] = m < p.M;
-        if (p.conv) {
+        if constexpr (CONV) {
             const int ohw = p.OH * p.OW;
             const int img = m / ohw;
             const int rem = m - img * ohw;
             const int oh = rem / p.OW, ow = rem - oh * p.OW;
             a_ih0[j] = oh * p.stride - p.pad;
             a_iw0[j] = ow * p.stride - p.pad;
-            a_row_off[j] = (uint32_t)(img * p.H * p.W);
+            a_pix[j] = (uint32_t)(img * p.H * p.W);
+            a_off[j] = 0;
         } else {
             a_ih0[j] = a_iw0[j] = 0;
-            a_row_off[j] = (uint32_t)m * (uint32_t)p.lda;
+            a_pix[j] = 0;
+            a_off[j] = a_ok[j] ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(c16 * EPC)) * (uint32_t)sizeof(T) : OOB;
         }
     }
-    uint32_t b_row_off[RB];
-    bool b_ok[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int n = n0 + r0 + 32 * j;
-        b_ok[j] = n < p.N;
-        b_row_off[j] = (uint32_t)n * (uint32_t)p.ldb;
+        b_off[j] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(c16 * EPC)) * (uint32_t)sizeof(T) : OOB;
     }
 
     u32x4 ra[RA], rb[RB];
 
     auto issue_loads = [&](int kt) {
         const int k0 = kt * BK;
-        const int kc = k0 + c16 * EPC;
-        const bool k_ok = kc < p.K;
-        if (p.conv) {
-            const int tap = k0 / p.Cin;            // a K-tile never straddles taps (Cin % BK == 0)
+        const bool k_ok = k0 + c16 * EPC < p.K;          // only false in a ragged last K-tile
+        uint32_t oa[RA], ob[RB];
+        int soff;
+        if constexpr (CONV) {
+            const int tap = k0 / p.Cin;                  // a K-tile never straddles taps (Cin % BK == 0)
             const int cin0 = k0 - tap * p.Cin + c16 * EPC;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
                 const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
-                const bool ok = a_ok[j] && k_ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                const uint32_t off = ((a_row_off[j] + (uint32_t)(ih * p.W + iw)) * (uint32_t)p.Cin + (uint32_t)cin0) * (uint32_t)sizeof(T);
-                ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : OOB, 0, 0);
+                const bool ok = a_ok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const uint32_t off = ((a_pix[j] + (uint32_t)(ih * p.W + iw)) * (uint32_t)p.Cin + (uint32_t)cin0) * (uint32_t)sizeof(T);
+                oa[j] = ok ? off : OOB;
             }
+            soff = 0;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) ob[j] = k_ok ? b_off[j] + (uint32_t)(k0 * (int)sizeof(T)) : OOB;
         } else {
+            soff = k0 * (int)sizeof(T);
 #pragma unroll
-            for (int j = 0; j < RA; ++j) {
-                const uint32_t off = (a_row_off[j] + (uint32_t)kc) * (uint32_t)sizeof(T);
-                ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (a_ok[j] && k_ok) ? off : OOB, 0, 0);
-            }
+            for (int j = 0; j < RA; ++j) oa[j] = k_ok ? a_off[j] : OOB;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) ob[j] = k_ok ? b_off[j] : OOB;
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const uint32_t off = (b_row_off[j] + (uint32_t)kc) * (uint32_t)sizeof(T);
-            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_ok[j] && k_ok) ? off : OOB, 0, 0);
-        }
+        for (int j = 0; j < RA; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa[j], soff, 0);
+#pragma unroll
+        for (int j = 0; j < RB; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ob[j], soff, 0);
     };
 
     auto store_lds = [&](int buf) {
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
     bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
     float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
+    const float* gg = p.gelu_grad_of ? p.gelu_grad_of + (long long)z * p.sGg : nullptr;
 
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
@@ -219,13 +226,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
+                float v = p.alpha * acc[i][j][r] + bv;
                 if (rowbias) v += rowbias[(long long)(m / p.rows_per_group) * p.ldrb + n];
                 if (res32) v += res32[(long long)m * p.ldres + n];
                 if (res16) v += bf16_to_f32(res16[(long long)m * p.ldres + n]);
                 if (cpre) cpre[(long long)m * p.ldpre + n] = v;
                 if (p.act == SQ_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == SQ_ACT_RELU) v = fmaxf(v, 0.f);
+                if (gg) v *= gelu_erf_grad(gg[(long long)m * p.ldgg + n]);
                 if (c32) c32[(long long)m * p.ldc + n] = v;
                 if (c16p) c16p[(long long)m * p.ldc + n] = f32_to_bf16(v);
                 if (c2) c2[(long long)m * p.ldc2 + n] = f32_to_bf16(v);
@@ -240,7 +248,8 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * 128;
     dim3 grid(tiles, 1, a.batch), block(256);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN>), grid, block, lds, stream, a);
+    if (a.conv) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, false>), grid, block, lds, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
@@ -274,8 +283,24 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
     } else {
         SQ_REQUIRE(a.lda % epc == 0, "gemm: lda=%d must be a multiple of %d", a.lda, epc);
     }
-    if (dtype == SQ_BF16) return launch_t<bf16_t>(a, stream);
-    if (dtype == SQ_F32) return launch_t<float>(a, stream);
-    sq_set_error("gemm: unknown dtype %d", dtype);
-    return SQ_ERR_ARG;
+    if (dtype != SQ_BF16 && dtype != SQ_F32) {
+        sq_set_error("gemm: unknown dtype %d", dtype);
+        return SQ_ERR_ARG;
+    }
+    int prof = -1;
+    if (sq_prof_on()) {
+        // algorithmic work of this launch: 2*M*N*K flops; operands read once + output written once
+        const double es = dtype == SQ_BF16 ? 2.0 : 4.0;
+        const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
+        const double a_elems = a.conv ? (double)a.M / (a.OH * a.OW) * a.H * a.W * a.Cin : (double)a.M * a.K;
+        const double bytes = (a_elems * es + (double)a.N * a.K * es) * a.batch +
+                             (double)a.M * a.N * a.batch * (a.out_dtype == SQ_BF16 ? 2.0 : 4.0);
+        char name[96];
+        snprintf(name, sizeof(name), "%s_%s_M%d_N%d_K%d_b%d", a.conv ? "conv" : "gemm", dtype == SQ_BF16 ? "bf16" : "f32",
+                 a.M, a.N, a.K, a.batch);
+        prof = sq_prof_begin(name, flops, bytes, stream);
+    }
+    const int rc = dtype == SQ_BF16 ? launch_t<bf16_t>(a, stream) : launch_t<float>(a, stream);
+    if (prof >= 0) sq_prof_end(prof, stream);
+    return rc;
 }

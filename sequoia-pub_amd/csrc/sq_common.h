@@ -14,6 +14,9 @@
 #define SQ_BF16 1
 
 void sq_set_error(const char* fmt, ...);
+bool sq_prof_on();
+int sq_prof_begin(const char* name, double flops, double bytes, hipStream_t st);
+void sq_prof_end(int idx, hipStream_t st);
 
 #define SQ_HIP_CHECK(expr)                                                        \
     do {                                                                          \
@@ -72,7 +75,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // d/dx of exact GELU
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
 
