@@ -93,6 +93,30 @@ def roofline_from_profile(step_fn, steps, dtype_name):
     return roof, recs
 
 
+def timed_cpu_sample(fn, units_per_call, budget_s=12.0, candidates=(8, 16, 32, 64, 128)):
+    """Time `fn` (a CPU oracle call) on this host: try a few torch thread counts once each (the
+    reference's many small per-head GEMMs do not scale to every core of a big host), keep the
+    fastest, then repeat it until ~budget_s seconds of CPU work.  Returns (units/s, threads, reps)."""
+    ncpu = os.cpu_count() or 1
+    best = None
+    for t in [c for c in candidates if c <= ncpu] or [ncpu]:
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, t)
+        if dt > budget_s:          # already slow: do not try more settings
+            break
+    torch.set_num_threads(best[1])
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or time.perf_counter() - t0 < budget_s:
+        fn()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return units_per_call * reps / dt, best[1], reps
+
+
 # ------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------
@@ -119,16 +143,12 @@ def workload_vis_fwd(args, rank, world, device):
         sd = {k: v.cpu() for k, v in model.state_dict().items()}
         nb = 8
         xc = x[:nb].cpu()
-        torch.set_num_threads(os.cpu_count())
-        with torch.no_grad():
-            vis_oracle.vis_forward(sd, xc)
-            t0 = time.perf_counter()
-            reps = 0
-            while time.perf_counter() - t0 < 10.0:
+
+        def call():
+            with torch.no_grad():
                 vis_oracle.vis_forward(sd, xc)
-                reps += 1
-            dt = time.perf_counter() - t0
-        return {"value": round(nb * reps / dt, 3), "unit": "slides/s", "cores": os.cpu_count(), "kind": "port",
+        rate, threads, reps = timed_cpu_sample(call, nb)
+        return {"value": round(rate, 3), "unit": "slides/s", "cores": threads, "kind": "port",
                 "sample": f"oracle.vis_oracle.vis_forward (torch-CPU fp32), {reps} x batch {nb} of the same tokens"}
 
     return dict(step=step, slides_per_step=B, cpu_baseline=cpu_baseline,
@@ -155,15 +175,14 @@ def workload_vis_train(args, rank, world, device):
         xc, yc = x[:nb].cpu(), y[:nb].cpu()
         m = {k: torch.zeros_like(v) for k, v in sd.items()}
         v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
-        torch.set_num_threads(os.cpu_count())
-        t0 = time.perf_counter()
-        reps = 0
-        while reps < 2 or time.perf_counter() - t0 < 12.0:
+        state = {"step": 0}
+
+        def call():
             _, _, grads = vis_oracle.vis_loss_and_grads(sd, xc, yc)
-            vis_oracle.adamw_step(sd, grads, m, v2, reps + 1)
-            reps += 1
-        dt = time.perf_counter() - t0
-        return {"value": round(nb * reps / dt, 3), "unit": "slides/s", "cores": os.cpu_count(), "kind": "port",
+            state["step"] += 1
+            vis_oracle.adamw_step(sd, grads, m, v2, state["step"])
+        rate, threads, reps = timed_cpu_sample(call, nb)
+        return {"value": round(rate, 3), "unit": "slides/s", "cores": threads, "kind": "port",
                 "sample": f"oracle ViS fwd+bwd+AdamW (torch-CPU fp32 autograd), {reps} steps x batch {nb}"}
 
     return dict(step=step, slides_per_step=B, cpu_baseline=cpu_baseline,
@@ -181,7 +200,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "vis_fwd"), choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "vis_train"), choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=64, help="slides per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")

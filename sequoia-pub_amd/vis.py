@@ -84,8 +84,7 @@ class _VisFunction(torch.autograd.Function):
     """forward = sq_vis_forward; backward = sq_vis_backward (grads w.r.t. the flat buffer and x)."""
 
     @staticmethod
-    def forward(ctx, flat, x, module):
-        need_grad = torch.is_grad_enabled() and (flat.requires_grad or x.requires_grad)
+    def forward(ctx, flat, x, module, need_grad):
         out = module._run_forward(x, save=need_grad)
         ctx.module = module
         ctx.need_x_grad = x.requires_grad
@@ -99,7 +98,7 @@ class _VisFunction(torch.autograd.Function):
         gflat, gx = module._run_backward(grad_out.contiguous(), ctx.batch, ctx.need_x_grad)
         if gx is not None:
             gx = gx.reshape(ctx.x_shape)
-        return gflat, gx, None
+        return gflat, gx, None, None
 
 
 class ViS(nn.Module, PyTorchModelHubMixin):
@@ -285,7 +284,8 @@ class ViS(nn.Module, PyTorchModelHubMixin):
             # spatial_vis/visualize.py:82 feeds [100, D]; the reference's rearrange turns that into
             # [100, 1, D] (+ pos-emb broadcast).  We implement the intended one-window = one sample.
             x = x.unsqueeze(0)
-        return _VisFunction.apply(self.flat, x, self)
+        need_grad = torch.is_grad_enabled() and (self.flat.requires_grad or x.requires_grad)
+        return _VisFunction.apply(self.flat, x, self, need_grad)
 
     def forward_literal_2d(self, x2d):
         """Bit-for-bit behaviour of the reference on a 2-D [100, D] input:
