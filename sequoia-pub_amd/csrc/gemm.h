@@ -30,7 +30,11 @@ struct GemmArgs {
     // implicit-GEMM convolution view of A: NHWC [n, H, W, Cin]; K = KH*KW*Cin, tap-major
     int conv = 0, H = 0, W = 0, Cin = 0, OH = 0, OW = 0, KW = 1, stride = 1, pad = 0;
     size_t a_bytes = 0, b_bytes = 0;   // extents of A and B for the buffer descriptors (< 2 GiB)
+    int vec_epi = 0;                   // set by sq_launch_gemm: all epilogue operands allow 16-byte accesses
+    int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };
 
 // dtype: SQ_F32 (v_mfma_f32_32x32x2_f32, exact fp32) or SQ_BF16 (v_mfma_f32_32x32x16_bf16)
 int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream);
+// experiment knobs (not part of the product ABI): key 0 = forced tile (WTM*10+WTN, 0 = auto), key 1 = dbg flags
+extern "C" int sq_dbg_set(int key, int value);

@@ -198,13 +198,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) issue_loads(kt + 1);
-        compute(kt & 1);
+        if (more && !(p.dbg & 2)) issue_loads(kt + 1);
+        if (!(p.dbg & 4)) compute(kt & 1);
         if (more) store_lds((kt + 1) & 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue ---------------------------------------------------------------------------
+    // Accumulators go through LDS (the K-loop buffers are free after the last barrier) so that the
+    // epilogue is a short rolled loop of 16-byte row-major accesses instead of 64 unrolled scalar
+    // stores per lane.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int col = wn * (WTN * 32) + j * 32 + l31;
+                stage[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
     const float* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
     const float* rowbias = p.rowbias ? p.rowbias + (long long)z * p.sRb : nullptr;
     const float* res32 = (p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
@@ -214,29 +230,53 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
     float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
     const float* gg = p.gelu_grad_of ? p.gelu_grad_of + (long long)z * p.sGg : nullptr;
+    if (p.dbg & 1) return;
 
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) {
-        const int n = n0 + wn * (WTN * 32) + j * 32 + l31;
-        if (n >= p.N) continue;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < WTM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (WTM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float v = p.alpha * acc[i][j][r] + bv;
-                if (rowbias) v += rowbias[(long long)(m / p.rows_per_group) * p.ldrb + n];
-                if (res32) v += res32[(long long)m * p.ldres + n];
-                if (res16) v += bf16_to_f32(res16[(long long)m * p.ldres + n]);
-                if (cpre) cpre[(long long)m * p.ldpre + n] = v;
-                if (p.act == SQ_ACT_GELU) v = gelu_erf(v);
-                else if (p.act == SQ_ACT_RELU) v = fmaxf(v, 0.f);
-                if (gg) v *= gelu_erf_grad(gg[(long long)m * p.ldgg + n]);
-                if (c32) c32[(long long)m * p.ldc + n] = v;
-                if (c16p) c16p[(long long)m * p.ldc + n] = f32_to_bf16(v);
-                if (c2) c2[(long long)m * p.ldc2 + n] = f32_to_bf16(v);
+    constexpr int BN4 = BN / 4;
+    const bool vec = p.vec_epi != 0;
+#pragma unroll 1
+    for (int idx = tid; idx < BM * BN4; idx += 256) {
+        const int row = idx / BN4, c4 = idx - row * BN4;
+        const int m = m0 + row, n = n0 + c4 * 4;
+        if (m >= p.M || n >= p.N) continue;
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + row * BN + c4 * 4);
+        float v[4] = {p.alpha * a4[0], p.alpha * a4[1], p.alpha * a4[2], p.alpha * a4[3]};
+        const int cnt = min(4, p.N - n);
+        const long long rb_row = rowbias ? (long long)(m / p.rows_per_group) * p.ldrb : 0;
+        if (vec && cnt == 4) {
+            if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+            if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + rb_row + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+            if (res32) { const f32x4 t = *reinterpret_cast<const f32x4*>(res32 + (long long)m * p.ldres + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+            if (res16) {
+                const u32x2 t = *reinterpret_cast<const u32x2*>(res16 + (long long)m * p.ldres + n);
+                v[0] += __uint_as_float(t[0] << 16); v[1] += __uint_as_float(t[0] & 0xffff0000u);
+                v[2] += __uint_as_float(t[1] << 16); v[3] += __uint_as_float(t[1] & 0xffff0000u);
+            }
+            if (cpre) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cpre + (long long)m * p.ldpre + n) = t; }
+            if (p.act == SQ_ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            else if (p.act == SQ_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (gg) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(gg + (long long)m * p.ldgg + n);
+                v[0] *= gelu_erf_grad(t[0]); v[1] *= gelu_erf_grad(t[1]); v[2] *= gelu_erf_grad(t[2]); v[3] *= gelu_erf_grad(t[3]);
+            }
+            if (c32) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(c32 + (long long)m * p.ldc + n) = t; }
+            if (c16p) { u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(c16p + (long long)m * p.ldc + n) = t; }
+            if (c2) { u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(c2 + (long long)m * p.ldc2 + n) = t; }
+        } else {
+            for (int e = 0; e < cnt; ++e) {
+                float x = v[e];
+                const int ne = n + e;
+                if (bias) x += bias[ne];
+                if (rowbias) x += rowbias[rb_row + ne];
+                if (res32) x += res32[(long long)m * p.ldres + ne];
+                if (res16) x += bf16_to_f32(res16[(long long)m * p.ldres + ne]);
+                if (cpre) cpre[(long long)m * p.ldpre + ne] = x;
+                if (p.act == SQ_ACT_GELU) x = gelu_erf(x);
+                else if (p.act == SQ_ACT_RELU) x = fmaxf(x, 0.f);
+                if (gg) x *= gelu_erf_grad(gg[(long long)m * p.ldgg + ne]);
+                if (c32) c32[(long long)m * p.ldc + ne] = x;
+                if (c16p) c16p[(long long)m * p.ldc + ne] = f32_to_bf16(x);
+                if (c2) c2[(long long)m * p.ldc2 + ne] = f32_to_bf16(x);
             }
         }
     }
@@ -254,8 +294,16 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return SQ_OK;
 }
 
+int g_force_tile = 0, g_dbg = 0;
+
 template <typename T>
-int launch_t(const GemmArgs& a, hipStream_t stream) {
+int launch_t(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    a.dbg |= g_dbg;
+    if (g_force_tile == 22) return launch_cfg<T, 2, 2>(a, stream);
+    if (g_force_tile == 21) return launch_cfg<T, 2, 1>(a, stream);
+    if (g_force_tile == 12) return launch_cfg<T, 1, 2>(a, stream);
+    if (g_force_tile == 11) return launch_cfg<T, 1, 1>(a, stream);
     // tile choice: fill >= 256 CUs when the problem allows; narrow N (Cout 64) gets BN = 64
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
     if (a.N <= 64) {
@@ -270,6 +318,13 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int sq_dbg_set(int key, int value) {
+    if (key == 0) g_force_tile = value;
+    else if (key == 1) g_dbg = value;
+    else return SQ_ERR_ARG;
+    return SQ_OK;
+}
 
 int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
     const int epc = dtype == SQ_BF16 ? 8 : 4;
@@ -287,6 +342,22 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
         sq_set_error("gemm: unknown dtype %d", dtype);
         return SQ_ERR_ARG;
     }
+    GemmArgs av = a;
+    {   // 16-byte epilogue accesses need every leading dimension / base / batch stride 4-element aligned
+        auto al = [](const void* ptr, int ld, long long st, int elem) {
+            return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
+        };
+        const int oe = a.out_dtype == SQ_BF16 ? 2 : 4, re = a.res_dtype == SQ_BF16 ? 2 : 4;
+        // bf16 outputs are written 8 bytes at a time: 8-byte alignment is enough for them
+        auto al8 = [](const void* ptr, int ld, long long st) {
+            return ptr == nullptr || (((uintptr_t)ptr % 8) == 0 && (ld * 2) % 8 == 0 && ((st * 2) % 8) == 0);
+        };
+        bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, 4) &&
+                  al(a.gelu_grad_of, a.ldgg, a.sGg, 4) && al8(a.C2, a.ldc2, a.sC2);
+        ok = ok && (oe == 4 ? al(a.C, a.ldc, a.sC, 4) : al8(a.C, a.ldc, a.sC));
+        ok = ok && (re == 4 ? al(a.res, a.ldres, a.sRes, 4) : al8(a.res, a.ldres, a.sRes));
+        av.vec_epi = ok ? 1 : 0;
+    }
     int prof = -1;
     if (sq_prof_on()) {
         // algorithmic work of this launch: 2*M*N*K flops; operands read once + output written once
@@ -300,7 +371,7 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
                  a.M, a.N, a.K, a.batch);
         prof = sq_prof_begin(name, flops, bytes, stream);
     }
-    const int rc = dtype == SQ_BF16 ? launch_t<bf16_t>(a, stream) : launch_t<float>(a, stream);
+    const int rc = dtype == SQ_BF16 ? launch_t<bf16_t>(av, stream) : launch_t<float>(av, stream);
     if (prof >= 0) sq_prof_end(prof, stream);
     return rc;
 }

@@ -1,0 +1,52 @@
+"""GPU experiment: time sq_linear (MFMA NT GEMM engine) per tile config / ablation switch and
+against torch.matmul (hipBLASLt) on the same operands.  Not part of the product or the tests."""
+import ctypes
+import sys, os
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sequoia_pub_amd
+from sequoia_pub_amd import _lib
+
+lib = _lib.lib()
+lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
+
+
+def time_fn(fn, iters=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3   # us
+
+
+def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6)):
+    tdt = torch.bfloat16 if dtype == _lib.SQ_BF16 else torch.float32
+    A = torch.randn(M, K, device="cuda").to(tdt)
+    W = torch.randn(N, K, device="cuda").to(tdt)
+    C = torch.empty(M, N, device="cuda")
+    flops = 2.0 * M * N * K
+    t = time_fn(lambda: torch.matmul(A, W.T))
+    print(f"M={M} N={N} K={K} {tdt}: torch.matmul {t:8.1f} us {flops / t / 1e6:8.1f} TF", flush=True)
+    for tile in tiles:
+        for dbg in dbgs:
+            lib.sq_dbg_set(0, tile)
+            lib.sq_dbg_set(1, dbg)
+            fn = lambda: _lib.check(lib.sq_linear(dtype, _lib.ptr(A), K, _lib.ptr(W), K, None, None, 0, 0, _lib.ptr(C), 0, N, M, N, K, _lib.stream_ptr()))
+            t = time_fn(fn)
+            print(f"   tile {tile} dbg {dbg}: {t:8.1f} us {flops / t / 1e6:8.1f} TF", flush=True)
+    lib.sq_dbg_set(0, 0)
+    lib.sq_dbg_set(1, 0)
+
+
+if __name__ == "__main__":
+    probe(6400, 1024, 1024, _lib.SQ_BF16)
+    probe(6400, 1024, 1024, _lib.SQ_F32, dbgs=(0, 1))
+    probe(8192, 8192, 8192, _lib.SQ_BF16, tiles=(22,), dbgs=(0, 1, 2))
+    probe(64, 1024, 1024, _lib.SQ_BF16, tiles=(12, 11), dbgs=(0,))
+    probe(64, 20820, 1024, _lib.SQ_BF16, tiles=(12, 11), dbgs=(0,))
+    probe(1024, 1024, 6400, _lib.SQ_BF16, tiles=(22, 21, 11), dbgs=(0,))
