@@ -117,6 +117,23 @@ int sq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
 int sq_batch_metrics(const float* pred, const float* target, int batch, int num_outputs, float* out3, void* scratch,
                      sq_stream_t stream);
 
+/* ------------------------------------------------------------------------------
+ * Per-slide k-Means + cluster means  (pre_processing/kmean_features.py:96-108:
+ *   KMeans(n_clusters=100, random_state=0).fit(features).labels_ ; per-label np.mean(...))
+ * scikit-learn semantics (k-means++ with 2+log(k) local trials, Lloyd, max_iter 300, tol 1e-4),
+ * batched over n_slides independent slides of n_samples x dim fp32 features each.
+ * The MT19937 draws are data-independent, so the host passes them in: first_center =
+ * RandomState(0).choice(n) and uniforms f64 [n_clusters-1, n_local_trials] (device memory).
+ * Outputs (device): labels i32 [S, n]; cluster_features f32 [S, k, dim] (may be NULL);
+ * seed_indices i32 [S, k] (may be NULL); n_iter i32 [S] (may be NULL).
+ * Synchronises the stream between Lloyd bursts (the stop decision is read on the host).
+ * ---------------------------------------------------------------------------- */
+size_t sq_kmeans_workspace_bytes(int n_slides, int n_samples, int dim, int n_clusters);
+int sq_kmeans_fit(const float* X, int n_slides, int n_samples, int dim, int n_clusters, int first_center,
+                  const double* uniforms, int n_local_trials, int max_iter, double tol, int32_t* labels,
+                  float* cluster_features, int32_t* seed_indices, int32_t* n_iter, void* workspace,
+                  size_t workspace_bytes, sq_stream_t stream);
+
 /* dst_bf16[i] = bf16(src[i]) -- refresh of the bf16 parameter shadow after an optimizer step */
 int sq_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, sq_stream_t stream);
 
@@ -126,9 +143,11 @@ int sq_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, sq_stream_t 
  * A [M,K] (lda) and W [N,K] (ldw) are `dtype` (f32 or bf16), bias f32 [N] or NULL,
  * residual f32 [M,N] (ldres) or NULL, act: 0 none, 1 exact-erf GELU, 2 ReLU,
  * C [M,N] (ldc) in out_dtype.  K, lda, ldw multiples of 16 bytes / element size.
+ * workspace (optional fp32 scratch, may be NULL): lets skinny problems run split-K.
  * ---------------------------------------------------------------------------- */
 int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual,
-              int ldres, int act, void* C, int out_dtype, int ldc, int M, int N, int K, sq_stream_t stream);
+              int ldres, int act, void* C, int out_dtype, int ldc, int M, int N, int K, void* workspace,
+              size_t workspace_bytes, sq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -72,12 +72,16 @@ def _declare(lib):
     lib.sq_adamw_step.argtypes = [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, f32, vp]
     lib.sq_batch_metrics.restype = i32
     lib.sq_batch_metrics.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.sq_kmeans_workspace_bytes.restype = sz
+    lib.sq_kmeans_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.sq_kmeans_fit.restype = i32
+    lib.sq_kmeans_fit.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, i32, ctypes.c_double, vp, vp, vp, vp, vp, sz, vp]
     lib.sq_prof_enable.restype = i32
     lib.sq_prof_enable.argtypes = [i32]
     lib.sq_prof_report.restype = i32
     lib.sq_prof_report.argtypes = [ctypes.c_char_p, sz]
     lib.sq_linear.restype = i32
-    lib.sq_linear.argtypes = [i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]
+    lib.sq_linear.argtypes = [i32, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, sz, vp]
     lib.sq_cast_f32_to_bf16.restype = i32
     lib.sq_cast_f32_to_bf16.argtypes = [vp, vp, sz, vp]
     for name, (res, args) in _OPTIONAL.items():

@@ -30,6 +30,10 @@ struct GemmArgs {
     // implicit-GEMM convolution view of A: NHWC [n, H, W, Cin]; K = KH*KW*Cin, tap-major
     int conv = 0, H = 0, W = 0, Cin = 0, OH = 0, OW = 0, KW = 1, stride = 1, pad = 0;
     size_t a_bytes = 0, b_bytes = 0;   // extents of A and B for the buffer descriptors (< 2 GiB)
+    // split-K: set splitk_ws (fp32 scratch) to allow it; the launcher picks the slice count
+    float* splitk_ws = nullptr;
+    size_t splitk_ws_bytes = 0;
+    int splitk = 1;                    // set by the launcher
     int vec_epi = 0;                   // set by sq_launch_gemm: all epilogue operands allow 16-byte accesses
     int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };

@@ -1,23 +1,38 @@
 // MFMA NT GEMM / implicit-GEMM convolution for gfx950 (MI355X).
 //
+//   C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias + rowbias + res) * GELU'(gelu_grad_of)
+//
 // Tile: 256 threads = 4 waves (2x2); each wave owns WTM x WTN MFMA tiles of 32x32.
-// K is walked in tiles of 128 bytes per row (64 bf16 / 32 fp32), staged
-// global -> VGPR -> LDS (register prefetch of tile t+1 under the MFMAs of tile t, two
-// LDS buffers, one barrier per K-tile).  LDS rows are 128 B, 16-B chunks XOR-swizzled
-// by (row>>1)&7 so every ds_read_b128 lane group touches 16 distinct 16-B slots.
-// Loads go through buffer descriptors: rows past M/N, K tails and convolution padding
-// are redirected to an out-of-range offset and read back as zero.
+// K is walked in tiles of 128 bytes per row (64 bf16 / 32 fp32).  Operand tiles go HBM/L2 -> LDS
+// directly (buffer_load ... lds, 16 B per lane, no VGPR round trip): a wave's 64 lanes fill 8
+// consecutive 128-B LDS rows, and the XOR swizzle that keeps ds_read_b128 conflict-free
+// (16-B chunk ^= (row>>1)&7) is applied on the SOURCE address, the LDS image stays lane-linear.
+// Tile t+1 is in flight while the MFMAs of tile t run (two LDS buffers, one barrier per K-tile).
+// Loads go through buffer descriptors: rows past M/N, K tails and convolution padding are
+// redirected to an out-of-range offset and land in LDS as zeros.
+// Epilogue: accumulators are staged through LDS and leave as 16-byte row-major accesses.
+// Split-K (deterministic): K-slices write fp32 partials, a second kernel sums them in slice
+// order and applies the same epilogue.
 //
 // fp32 path: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) -- the parity mode.
 // bf16 path: v_mfma_f32_32x32x16_bf16, fp32 accumulate -- the perf mode.
 #include "gemm.h"
+
 #include <cstdio>
 
 namespace {
 
 constexpr uint32_t OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ u32x4 lds_read128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// 16 B per lane, HBM/L2 -> LDS without a VGPR round trip.  LDS destination = lds_base + lane*16
+// (lane-linear); the source offset is per lane.  Kept in a non-template helper: the host pass of a
+// kernel TEMPLATE that names this builtin directly silently drops the kernel's launch stub.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, uint32_t voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_base, 16, voffset, soffset, 0, 0);
+}
 
 template <typename T> struct Mma;
 
@@ -39,12 +54,64 @@ template <> struct Mma<bf16_t> {
     }
 };
 
+// Epilogue of one 4-wide chunk (row m, columns n..n+cnt-1); v holds the raw accumulators.
+__device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m, int n, float (&v)[4], int cnt, bool vec) {
+    const float* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+    const float* rowbias = p.rowbias ? p.rowbias + (long long)z * p.sRb : nullptr;
+    const float* res32 = (p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
+    const bf16_t* res16 = (p.res && p.res_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes : nullptr;
+    float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
+    bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
+    bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
+    float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
+    const float* gg = p.gelu_grad_of ? p.gelu_grad_of + (long long)z * p.sGg : nullptr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    const long long rb_row = rowbias ? (long long)(m / p.rows_per_group) * p.ldrb : 0;
+    if (vec && cnt == 4) {
+        if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+        if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + rb_row + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+        if (res32) { const f32x4 t = *reinterpret_cast<const f32x4*>(res32 + (long long)m * p.ldres + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+        if (res16) {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(res16 + (long long)m * p.ldres + n);
+            v[0] += __uint_as_float(t[0] << 16); v[1] += __uint_as_float(t[0] & 0xffff0000u);
+            v[2] += __uint_as_float(t[1] << 16); v[3] += __uint_as_float(t[1] & 0xffff0000u);
+        }
+        if (cpre) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cpre + (long long)m * p.ldpre + n) = t; }
+        if (p.act == SQ_ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+        else if (p.act == SQ_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (gg) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(gg + (long long)m * p.ldgg + n);
+            v[0] *= gelu_erf_grad(t[0]); v[1] *= gelu_erf_grad(t[1]); v[2] *= gelu_erf_grad(t[2]); v[3] *= gelu_erf_grad(t[3]);
+        }
+        if (c32) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(c32 + (long long)m * p.ldc + n) = t; }
+        if (c16p) { u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(c16p + (long long)m * p.ldc + n) = t; }
+        if (c2) { u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(c2 + (long long)m * p.ldc2 + n) = t; }
+    } else {
+        for (int e = 0; e < cnt; ++e) {
+            float x = v[e];
+            const int ne = n + e;
+            if (bias) x += bias[ne];
+            if (rowbias) x += rowbias[rb_row + ne];
+            if (res32) x += res32[(long long)m * p.ldres + ne];
+            if (res16) x += bf16_to_f32(res16[(long long)m * p.ldres + ne]);
+            if (cpre) cpre[(long long)m * p.ldpre + ne] = x;
+            if (p.act == SQ_ACT_GELU) x = gelu_erf(x);
+            else if (p.act == SQ_ACT_RELU) x = fmaxf(x, 0.f);
+            if (gg) x *= gelu_erf_grad(gg[(long long)m * p.ldgg + ne]);
+            if (c32) c32[(long long)m * p.ldc + ne] = x;
+            if (c16p) c16p[(long long)m * p.ldc + ne] = f32_to_bf16(x);
+            if (c2) c2[(long long)m * p.ldc2 + ne] = f32_to_bf16(x);
+        }
+    }
+}
+
 template <typename T, int WTM, int WTN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;                // K elements per tile (128 B)
-    constexpr int RA = BM / 32, RB = BN / 32;  // chunks per thread per tile
+    constexpr int RA = BM / 32, RB = BN / 32;  // LDS-DMA instructions per thread per tile
     constexpr int TILE_BYTES = (BM + BN) * 128;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,13 +141,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)a_rem, 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)b_rem, 0x00020000);
 
-    const int c16 = tid & 7;      // 16-B chunk inside the 128-B K-tile row
-    const int r0 = tid >> 3;      // row inside a 32-row group
+    const int r0 = tid >> 3;                       // row inside a 32-row group (LDS image: lane-linear)
+    const int gc = (tid & 7) ^ ((r0 >> 1) & 7);    // 16-B chunk of the SOURCE row this lane fetches
 
-    // per-thread row bookkeeping.  Plain GEMM: the byte offset of each row's chunk is loop-invariant
-    // (the K-tile offset travels in the scalar soffset operand), so the K loop issues its loads
-    // back-to-back with no address arithmetic.  Conv: one offset per (row, tap).
-    uint32_t a_off[RA], b_off[RB];      // byte offsets at k = 0 (OOB when the row is out of range)
+    // Loop-invariant byte offsets (the K-tile offset travels in the scalar soffset operand).
+    uint32_t a_off[RA], b_off[RB];
     int a_ih0[RA], a_iw0[RA];
     uint32_t a_pix[RA];
     bool a_ok[RA];
@@ -100,25 +165,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         } else {
             a_ih0[j] = a_iw0[j] = 0;
             a_pix[j] = 0;
-            a_off[j] = a_ok[j] ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(c16 * EPC)) * (uint32_t)sizeof(T) : OOB;
+            a_off[j] = a_ok[j] ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(gc * EPC)) * (uint32_t)sizeof(T) : OOB;
         }
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int n = n0 + r0 + 32 * j;
-        b_off[j] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(c16 * EPC)) * (uint32_t)sizeof(T) : OOB;
+        b_off[j] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(gc * EPC)) * (uint32_t)sizeof(T) : OOB;
     }
 
-    u32x4 ra[RA], rb[RB];
-
-    auto issue_loads = [&](int kt) {
+    // tile kt -> LDS buffer buf, asynchronously (completion: vmcnt, drained by the barrier's fence)
+    auto issue_loads = [&](int kt, int buf) {
         const int k0 = kt * BK;
-        const bool k_ok = k0 + c16 * EPC < p.K;          // only false in a ragged last K-tile
+        const bool k_ok = k0 + gc * EPC < p.K;           // only false in a ragged last K-tile
+        char* sa = smem + buf * TILE_BYTES + wave * (8 * 128);
+        char* sb = sa + BM * 128;
         uint32_t oa[RA], ob[RB];
         int soff;
         if constexpr (CONV) {
             const int tap = k0 / p.Cin;                  // a K-tile never straddles taps (Cin % BK == 0)
-            const int cin0 = k0 - tap * p.Cin + c16 * EPC;
+            const int cin0 = k0 - tap * p.Cin + gc * EPC;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
@@ -138,24 +204,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
             for (int j = 0; j < RB; ++j) ob[j] = k_ok ? b_off[j] : OOB;
         }
 #pragma unroll
-        for (int j = 0; j < RA; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa[j], soff, 0);
+        for (int j = 0; j < RA; ++j)
+            glds16(rsA, sa + j * (32 * 128), oa[j], soff);
 #pragma unroll
-        for (int j = 0; j < RB; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ob[j], soff, 0);
-    };
-
-    auto store_lds = [&](int buf) {
-        char* sa = smem + buf * TILE_BYTES;
-        char* sb = sa + BM * 128;
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const int row = r0 + 32 * j;
-            *reinterpret_cast<u32x4*>(sa + row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4)) = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int row = r0 + 32 * j;
-            *reinterpret_cast<u32x4*>(sb + row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4)) = rb[j];
-        }
+        for (int j = 0; j < RB; ++j)
+            glds16(rsB, sb + j * (32 * 128), ob[j], soff);
     };
 
     f32x16 acc[WTM][WTN];
@@ -192,22 +245,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         }
     };
 
-    const int nk = (p.K + BK - 1) / BK;
-    issue_loads(0);
-    store_lds(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more && !(p.dbg & 2)) issue_loads(kt + 1);
-        if (!(p.dbg & 4)) compute(kt & 1);
-        if (more) store_lds((kt + 1) & 1);
+    // this block's K-tile range (split-K slices are contiguous runs of K-tiles)
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    const int kt_lo = blockIdx.y * per;
+    const int kt_hi = min(nk_all, kt_lo + per);
+
+    if (kt_lo < kt_hi) {
+        issue_loads(kt_lo, 0);
         __syncthreads();
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            const int cur = (kt - kt_lo) & 1;
+            if (kt + 1 < kt_hi && !(p.dbg & 2)) issue_loads(kt + 1, cur ^ 1);
+            if (!(p.dbg & 4)) compute(cur);
+            __syncthreads();
+        }
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------
-    // Accumulators go through LDS (the K-loop buffers are free after the last barrier) so that the
-    // epilogue is a short rolled loop of 16-byte row-major accesses instead of 64 unrolled scalar
-    // stores per lane.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
@@ -220,19 +275,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
                 stage[row * BN + col] = acc[i][j][r];
             }
     __syncthreads();
-
-    const float* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
-    const float* rowbias = p.rowbias ? p.rowbias + (long long)z * p.sRb : nullptr;
-    const float* res32 = (p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
-    const bf16_t* res16 = (p.res && p.res_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes : nullptr;
-    float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
-    bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
-    bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
-    float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
-    const float* gg = p.gelu_grad_of ? p.gelu_grad_of + (long long)z * p.sGg : nullptr;
     if (p.dbg & 1) return;
 
     constexpr int BN4 = BN / 4;
+    if (p.splitk > 1) {
+        // raw fp32 partial of this K-slice: ws[z][slice][M][N] (N % 4 == 0 enforced by the launcher)
+        float* part = p.splitk_ws + ((size_t)z * p.splitk + blockIdx.y) * (size_t)p.M * p.N;
+#pragma unroll 1
+        for (int idx = tid; idx < BM * BN4; idx += 256) {
+            const int row = idx / BN4, c4 = idx - row * BN4;
+            const int m = m0 + row, n = n0 + c4 * 4;
+            if (m < p.M && n < p.N)
+                *reinterpret_cast<f32x4*>(part + (size_t)m * p.N + n) = *reinterpret_cast<const f32x4*>(stage + row * BN + c4 * 4);
+        }
+        return;
+    }
     const bool vec = p.vec_epi != 0;
 #pragma unroll 1
     for (int idx = tid; idx < BM * BN4; idx += 256) {
@@ -240,45 +297,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         const int m = m0 + row, n = n0 + c4 * 4;
         if (m >= p.M || n >= p.N) continue;
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + row * BN + c4 * 4);
-        float v[4] = {p.alpha * a4[0], p.alpha * a4[1], p.alpha * a4[2], p.alpha * a4[3]};
-        const int cnt = min(4, p.N - n);
-        const long long rb_row = rowbias ? (long long)(m / p.rows_per_group) * p.ldrb : 0;
-        if (vec && cnt == 4) {
-            if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-            if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + rb_row + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-            if (res32) { const f32x4 t = *reinterpret_cast<const f32x4*>(res32 + (long long)m * p.ldres + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-            if (res16) {
-                const u32x2 t = *reinterpret_cast<const u32x2*>(res16 + (long long)m * p.ldres + n);
-                v[0] += __uint_as_float(t[0] << 16); v[1] += __uint_as_float(t[0] & 0xffff0000u);
-                v[2] += __uint_as_float(t[1] << 16); v[3] += __uint_as_float(t[1] & 0xffff0000u);
-            }
-            if (cpre) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cpre + (long long)m * p.ldpre + n) = t; }
-            if (p.act == SQ_ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-            else if (p.act == SQ_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            if (gg) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(gg + (long long)m * p.ldgg + n);
-                v[0] *= gelu_erf_grad(t[0]); v[1] *= gelu_erf_grad(t[1]); v[2] *= gelu_erf_grad(t[2]); v[3] *= gelu_erf_grad(t[3]);
-            }
-            if (c32) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(c32 + (long long)m * p.ldc + n) = t; }
-            if (c16p) { u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(c16p + (long long)m * p.ldc + n) = t; }
-            if (c2) { u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(c2 + (long long)m * p.ldc2 + n) = t; }
-        } else {
-            for (int e = 0; e < cnt; ++e) {
-                float x = v[e];
-                const int ne = n + e;
-                if (bias) x += bias[ne];
-                if (rowbias) x += rowbias[rb_row + ne];
-                if (res32) x += res32[(long long)m * p.ldres + ne];
-                if (res16) x += bf16_to_f32(res16[(long long)m * p.ldres + ne]);
-                if (cpre) cpre[(long long)m * p.ldpre + ne] = x;
-                if (p.act == SQ_ACT_GELU) x = gelu_erf(x);
-                else if (p.act == SQ_ACT_RELU) x = fmaxf(x, 0.f);
-                if (gg) x *= gelu_erf_grad(gg[(long long)m * p.ldgg + ne]);
-                if (c32) c32[(long long)m * p.ldc + ne] = x;
-                if (c16p) c16p[(long long)m * p.ldc + ne] = f32_to_bf16(x);
-                if (c2) c2[(long long)m * p.ldc2 + ne] = f32_to_bf16(x);
-            }
+        float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+        epi_apply(p, z, m, n, v, min(4, p.N - n), vec);
+    }
+}
+
+// sums the K-slice partials in slice order, then the normal epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+    const int N4 = p.N / 4;
+    const size_t total = (size_t)p.M * N4;
+    const int z = blockIdx.z;
+    const float* base = p.splitk_ws + (size_t)z * p.splitk * (size_t)p.M * p.N;
+    const bool vec = p.vec_epi != 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / N4), n = (int)(idx - (size_t)m * N4) * 4;
+        f32x4 s = *reinterpret_cast<const f32x4*>(base + (size_t)m * p.N + n);
+        for (int k = 1; k < p.splitk; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(base + (size_t)k * p.M * p.N + (size_t)m * p.N + n);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
         }
+        float v[4] = {s[0], s[1], s[2], s[3]};
+        epi_apply(p, z, m, n, v, 4, vec);
     }
 }
 
@@ -287,33 +326,52 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * 128;
-    dim3 grid(tiles, 1, a.batch), block(256);
+    dim3 grid(tiles, a.splitk, a.batch), block(256);
     if (a.conv) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, false>), grid, block, lds, stream, a);
     SQ_LAUNCH_CHECK();
+    if (a.splitk > 1) {
+        size_t nb = ((size_t)a.M * (a.N / 4) + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb, 1, a.batch), dim3(256), 0, stream, a);
+        SQ_LAUNCH_CHECK();
+    }
     return SQ_OK;
 }
 
-int g_force_tile = 0, g_dbg = 0;
+int g_force_tile = 0, g_dbg = 0, g_force_split = 0;
 
 template <typename T>
 int launch_t(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     a.dbg |= g_dbg;
-    if (g_force_tile == 22) return launch_cfg<T, 2, 2>(a, stream);
-    if (g_force_tile == 21) return launch_cfg<T, 2, 1>(a, stream);
-    if (g_force_tile == 12) return launch_cfg<T, 1, 2>(a, stream);
-    if (g_force_tile == 11) return launch_cfg<T, 1, 1>(a, stream);
-    // tile choice: fill >= 256 CUs when the problem allows; narrow N (Cout 64) gets BN = 64
-    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
-    if (a.N <= 64) {
-        if ((long long)((a.M + 127) / 128) * a.batch >= 256) return launch_cfg<T, 2, 1>(a, stream);
-        return launch_cfg<T, 1, 1>(a, stream);
+    const int epc = 16 / (int)sizeof(T);
+    auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * a.batch; };
+    // 128x128 whenever both extents allow it (a short grid is filled by split-K below, which measured
+    // faster than shrinking the tile); narrow problems take the matching 64-wide tile
+    int tile;
+    const bool can_split = a.splitk_ws != nullptr && a.K >= 16 * 8 * epc;
+    if (a.N <= 64) tile = blocks(128, 64) >= 256 ? 21 : 11;
+    else if (a.M <= 64) tile = blocks(64, 128) >= 256 ? 12 : 11;
+    else if (blocks(128, 128) >= 256 || can_split) tile = 22;
+    else tile = 11;
+    if (g_force_tile) tile = g_force_tile;
+    const int bm = tile / 10 * 64, bn = tile % 10 * 64;
+    // split-K when the grid cannot fill the chip and K is long enough to be worth slicing
+    a.splitk = 1;
+    const int nk = (a.K + 8 * epc - 1) / (8 * epc);
+    const long long nb = blocks(bm, bn);
+    if (a.splitk_ws && a.N % 4 == 0 && nb < 256 && nk >= 4) {
+        long long s = (512 + nb - 1) / nb;
+        if (s > nk / 2) s = nk / 2;
+        if (s > 32) s = 32;
+        while (s > 1 && (size_t)s * a.M * a.N * a.batch * sizeof(float) > a.splitk_ws_bytes) --s;
+        if (s > 1) a.splitk = (int)s;
     }
-    if (a.M <= 64) return launch_cfg<T, 1, 2>(a, stream);
-    if (t128 >= 512) return launch_cfg<T, 2, 2>(a, stream);
-    const long long t64n = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * a.batch;
-    if (t64n >= 384) return launch_cfg<T, 2, 1>(a, stream);
+    if (g_force_split > 0 && a.splitk_ws) a.splitk = g_force_split;
+    if (tile == 22) return launch_cfg<T, 2, 2>(a, stream);
+    if (tile == 21) return launch_cfg<T, 2, 1>(a, stream);
+    if (tile == 12) return launch_cfg<T, 1, 2>(a, stream);
     return launch_cfg<T, 1, 1>(a, stream);
 }
 
@@ -322,6 +380,7 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
+    else if (key == 2) g_force_split = value;
     else return SQ_ERR_ARG;
     return SQ_OK;
 }
@@ -343,19 +402,18 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
         return SQ_ERR_ARG;
     }
     GemmArgs av = a;
-    {   // 16-byte epilogue accesses need every leading dimension / base / batch stride 4-element aligned
+    {   // 16-byte epilogue accesses need every leading dimension / base / batch stride aligned
         auto al = [](const void* ptr, int ld, long long st, int elem) {
             return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
         };
-        const int oe = a.out_dtype == SQ_BF16 ? 2 : 4, re = a.res_dtype == SQ_BF16 ? 2 : 4;
-        // bf16 outputs are written 8 bytes at a time: 8-byte alignment is enough for them
+        // bf16 rows are written 8 bytes at a time: 8-byte alignment is enough for them
         auto al8 = [](const void* ptr, int ld, long long st) {
             return ptr == nullptr || (((uintptr_t)ptr % 8) == 0 && (ld * 2) % 8 == 0 && ((st * 2) % 8) == 0);
         };
         bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, 4) &&
                   al(a.gelu_grad_of, a.ldgg, a.sGg, 4) && al8(a.C2, a.ldc2, a.sC2);
-        ok = ok && (oe == 4 ? al(a.C, a.ldc, a.sC, 4) : al8(a.C, a.ldc, a.sC));
-        ok = ok && (re == 4 ? al(a.res, a.ldres, a.sRes, 4) : al8(a.res, a.ldres, a.sRes));
+        ok = ok && (a.out_dtype == SQ_F32 ? al(a.C, a.ldc, a.sC, 4) : al8(a.C, a.ldc, a.sC));
+        ok = ok && (a.res_dtype == SQ_F32 ? al(a.res, a.ldres, a.sRes, 4) : al8(a.res, a.ldres, a.sRes));
         av.vec_epi = ok ? 1 : 0;
     }
     int prof = -1;

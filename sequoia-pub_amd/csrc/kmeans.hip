@@ -1,0 +1,593 @@
+// Per-slide k-Means(100) + cluster means on the GPU, batched over slides.
+//
+// Stands behind pre_processing/kmean_features.py:96-108:
+//     KMeans(n_clusters=100, random_state=0).fit(features).labels_ ; per-label np.mean
+// i.e. scikit-learn's KMeans defaults (k-means++ seeding with 2+log(k) local trials, Lloyd,
+// max_iter 300, tol 1e-4) with the arithmetic defined in oracle/kmeans_oracle.py:
+//   * centring: column mean by adding rows in index order in fp32, X - mean in fp32
+//   * seeding distances  fl32(max(0, (-2 x.c + |x|^2) + |c|^2)) with fp64 dot products -- every
+//     candidate is a data point, so all of them come from ONE fp64 Gram matrix G = Xc Xc^T
+//     (v_mfma_f64_16x16x4_f64); the 99 dependent seeding steps then only read rows of G
+//   * potentials fl32(sum_fp64), cumsum in fp64, searchsorted(side=left), first-minimum argmin
+//   * Lloyd: |c|^2 - 2 x.c in fp64 on fp32 centres (fp64 MFMA), strict-< argmin, fp64 member
+//     sums in index order, fl32(sum/count), empty-cluster relocation, centre-shift / label stop rule
+//   * cluster means of the ORIGINAL features: member rows added in index order in fp32, / count
+// One workgroup per slide runs the whole seeding loop; slides are independent (grid dimension).
+#include "../../include/sequoia_hip.h"
+#include "sq_common.h"
+
+namespace {
+
+constexpr int KM_THREADS = 1024;
+constexpr int KM_MAX_TRIALS = 8;
+constexpr int KM_MAX_K = 256;
+
+struct KmState {          // per slide, device memory
+    int iter;             // Lloyd iterations run
+    int done;             // 1 once converged / max_iter reached
+    int strict;           // labels unchanged between two iterations
+    int n_empty;          // empty clusters found in the current iteration
+    double tol;           // 1e-4 * mean(var(X, axis=0))
+    double shift;         // sum of squared centre shifts of the current iteration
+};
+
+// ------------------------------------------------------------------------------------------
+// block-wide helpers (blockDim.x multiple of 64, <= 1024)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_reduce_sum(double v, double* sh /*[16]*/) {
+    v = wave_sum_f64(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int i = 0; i < nw; ++i) r += sh[i];     // same order on every thread -> identical result
+    return r;
+}
+
+__device__ __forceinline__ int block_reduce_sum_int(int v, int* sh /*[16]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    int r = 0;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// 1. centring + tolerance
+// ------------------------------------------------------------------------------------------
+// thread = column: rows added in index order (numpy's axis-0 reduction order), fp32
+__global__ void km_center_kernel(const float* __restrict__ X, float* __restrict__ Xc, double* __restrict__ colvar, int n, int D) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t base = (size_t)blockIdx.y * n * D;
+    if (d >= D) return;
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += X[base + (size_t)i * D + d];
+    const float mean = acc / (float)n;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const float x = X[base + (size_t)i * D + d];
+        Xc[base + (size_t)i * D + d] = x - mean;
+        s += (double)x;
+    }
+    const double m64 = s / n;
+    for (int i = 0; i < n; ++i) {
+        const double t = (double)X[base + (size_t)i * D + d] - m64;
+        q += t * t;
+    }
+    colvar[(size_t)blockIdx.y * D + d] = q / n;
+}
+
+__global__ void km_tol_kernel(const double* __restrict__ colvar, KmState* __restrict__ st, int D, double tol_rel) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) s += colvar[(size_t)blockIdx.x * D + d];
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) {
+        KmState& k = st[blockIdx.x];
+        k.iter = 0; k.done = 0; k.strict = 0; k.n_empty = 0; k.shift = 0.0;
+        k.tol = s / D * tol_rel;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 2. fp64 MFMA GEMM with fp32 operands:  C[M,N] (f64) = A[M,K] . B[N,K]^T   (batched over slides)
+//    block 64x64, 4 waves x (2x2 tiles of 16x16), K-chunk 32 staged in LDS as [k][row] doubles
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void km_dgemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          double* __restrict__ C, int M, int N, int K, long long sA,
+                                                          long long sB, long long sC) {
+    __shared__ double sa[32][64 + 2];
+    __shared__ double sb[32][64 + 2];
+    A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // loader: thread -> (row = tid / 4 within 64, k4 = tid % 4 ... two passes of 16 k each)
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int kk = k0 + half * 16 + lk;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (m0 + lrow < M && kk < K) va = *reinterpret_cast<const float4*>(A + (size_t)(m0 + lrow) * K + kk);
+            if (n0 + lrow < N && kk < K) vb = *reinterpret_cast<const float4*>(B + (size_t)(n0 + lrow) * K + kk);
+            const int kr = half * 16 + lk;
+            sa[kr + 0][lrow] = va.x; sa[kr + 1][lrow] = va.y; sa[kr + 2][lrow] = va.z; sa[kr + 3][lrow] = va.w;
+            sb[kr + 0][lrow] = vb.x; sb[kr + 1][lrow] = vb.y; sb[kr + 2][lrow] = vb.z; sb[kr + 3][lrow] = vb.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 32; ks += 4) {
+            const int k = ks + (lane >> 4);
+            double fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = sa[k][wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = sb[k][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+                const int n = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (m < M && n < N) C[(size_t)m * N + n] = acc[i][j][r];
+            }
+}
+
+// ------------------------------------------------------------------------------------------
+// 3. k-means++ seeding: one workgroup per slide, all k-1 dependent steps inside the kernel
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float seed_dist(const double* G, int n, int c, int j, double njj) {
+    // pairwise.py:647-651: d = -2 X.Y^T; d += XX; d += YY; cast fp32; max(., 0)   (njj = |x_j|^2 = G[j][j])
+    double d = -2.0 * G[(size_t)c * n + j];
+    d += G[(size_t)c * n + c];
+    d += njj;
+    const float f = (float)d;
+    return f > 0.f ? f : 0.f;
+}
+
+template <int PTS>   // points per thread (n <= PTS * blockDim.x)
+__global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __restrict__ Gall, const double* __restrict__ uniforms,
+                                                             int first, int n, int k, int trials, int* __restrict__ seeds) {
+    __shared__ double sh[16];
+    __shared__ int shi[16];
+    __shared__ double scan_w[16];
+    __shared__ int s_cand[KM_MAX_TRIALS];
+    const double* G = Gall + (size_t)blockIdx.x * n * n;
+    int* out = seeds + (size_t)blockIdx.x * k;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+
+    // thread owns the CONTIGUOUS points [tid*PTS, tid*PTS+PTS) so the scan is a plain blocked scan
+    float closest[PTS];
+    double nrm[PTS];
+#pragma unroll
+    for (int q = 0; q < PTS; ++q) {
+        const int j = tid * PTS + q;
+        nrm[q] = j < n ? G[(size_t)j * n + j] : 0.0;
+        closest[q] = j < n ? seed_dist(G, n, first, j, nrm[q]) : 0.f;
+    }
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < PTS; ++q) part += (double)closest[q];
+    float pot = (float)block_reduce_sum(part, sh);
+    if (tid == 0) out[0] = first;
+
+    for (int c = 1; c < k; ++c) {
+        // stable_cumsum (fp64) of closest: per-thread serial, wave scan, block scan
+        double run = 0.0, incl[PTS];
+#pragma unroll
+        for (int q = 0; q < PTS; ++q) { run += (double)closest[q]; incl[q] = run; }
+        double wscan = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(wscan, o, 64);
+            if (lane >= o) wscan += t;
+        }
+        __syncthreads();
+        if (lane == 63) scan_w[wv] = wscan;
+        __syncthreads();
+        double woff = 0.0;
+        for (int i = 0; i < wv; ++i) woff += scan_w[i];
+        const double excl = woff + wscan - run;          // sum of everything before this thread's points
+        // candidates: searchsorted(cumsum, u * pot, side='left') = #{cum < value}, clipped to n-1
+        for (int t = 0; t < trials; ++t) {
+            const double rv = uniforms[(size_t)(c - 1) * trials + t] * (double)pot;
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < PTS; ++q)
+                if (tid * PTS + q < n && excl + incl[q] < rv) ++cnt;
+            cnt = block_reduce_sum_int(cnt, shi);
+            if (tid == 0) s_cand[t] = cnt > n - 1 ? n - 1 : cnt;
+        }
+        __syncthreads();
+        // potentials of the candidates
+        float best_pot = 0.f;
+        int best_t = 0;
+        for (int t = 0; t < trials; ++t) {
+            const int cand = s_cand[t];
+            double p = 0.0;
+#pragma unroll
+            for (int q = 0; q < PTS; ++q) {
+                const int j = tid * PTS + q;
+                if (j < n) p += (double)fminf(closest[q], seed_dist(G, n, cand, j, nrm[q]));
+            }
+            const float pt = (float)block_reduce_sum(p, sh);
+            if (t == 0 || pt < best_pot) { best_pot = pt; best_t = t; }     // np.argmin: first minimum
+        }
+        const int chosen = s_cand[best_t];
+        pot = best_pot;
+#pragma unroll
+        for (int q = 0; q < PTS; ++q) {
+            const int j = tid * PTS + q;
+            if (j < n) closest[q] = fminf(closest[q], seed_dist(G, n, chosen, j, nrm[q]));
+        }
+        if (tid == 0) out[c] = chosen;
+        __syncthreads();
+    }
+}
+
+__global__ void km_gather_centers_kernel(const float* __restrict__ Xc, const int* __restrict__ seeds, float* __restrict__ centers,
+                                         int n, int D, int k) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int src = seeds[(size_t)s * k + c];
+    for (int d = threadIdx.x; d < D; d += blockDim.x)
+        centers[((size_t)s * k + c) * D + d] = Xc[((size_t)s * n + src) * D + d];
+}
+
+// ------------------------------------------------------------------------------------------
+// 4. Lloyd iteration pieces (every kernel returns at once for slides that are done)
+// ------------------------------------------------------------------------------------------
+// labels[j] = argmin_c (|c|^2 - 2 x_j.c), strict '<' (first minimum); dots from the fp64 GEMM
+__global__ void km_assign_kernel(const double* __restrict__ dots, const float* __restrict__ centers, int* __restrict__ labels,
+                                 const KmState* __restrict__ st, int n, int D, int k, int force) {
+    __shared__ double cn[KM_MAX_K];
+    const int s = blockIdx.y;
+    if (st[s].done && !force) return;
+    for (int c = threadIdx.x >> 6; c < k; c += blockDim.x >> 6) {       // wave per centre: |c|^2 in fp64
+        const float* cr = centers + ((size_t)s * k + c) * D;
+        double a = 0.0;
+        for (int d = threadIdx.x & 63; d < D; d += 64) a += (double)cr[d] * (double)cr[d];
+        a = wave_sum_f64(a);
+        if ((threadIdx.x & 63) == 0) cn[c] = a;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double* dr = dots + ((size_t)s * n + j) * k;
+    double best = cn[0] - 2.0 * dr[0];
+    int lab = 0;
+    for (int c = 1; c < k; ++c) {
+        const double v = cn[c] - 2.0 * dr[c];
+        if (v < best) { best = v; lab = c; }
+    }
+    labels[(size_t)s * n + j] = lab;
+}
+
+// counting sort of point ids by label, stable in the point index: members[off[c] .. off[c+1])
+__global__ __launch_bounds__(KM_THREADS) void km_members_kernel(const int* __restrict__ labels, int* __restrict__ members,
+                                                                int* __restrict__ offsets, const KmState* __restrict__ st, int n,
+                                                                int k, int force) {
+    __shared__ int slab[4096];
+    __shared__ int soff[KM_MAX_K + 1];
+    const int s = blockIdx.x;
+    if (st[s].done && !force) return;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) slab[j] = labels[(size_t)s * n + j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < k; c += blockDim.x) {
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) cnt += slab[j] == c;
+        soff[c + 1] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        soff[0] = 0;
+        for (int c = 0; c < k; ++c) soff[c + 1] += soff[c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const int lab = slab[j];
+        int rank = 0;
+        for (int i = 0; i < j; ++i) rank += slab[i] == lab;
+        members[(size_t)s * n + soff[lab] + rank] = j;
+    }
+    for (int c = threadIdx.x; c <= k; c += blockDim.x) offsets[(size_t)s * (k + 1) + c] = soff[c];
+}
+
+// sums[c, d] = sum over members (index order) of Xc in fp64
+__global__ void km_sums_kernel(const float* __restrict__ Xc, const int* __restrict__ members, const int* __restrict__ offsets,
+                               double* __restrict__ sums, const KmState* __restrict__ st, int n, int D, int k) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    if (st[s].done) return;
+    const int lo = offsets[(size_t)s * (k + 1) + c], hi = offsets[(size_t)s * (k + 1) + c + 1];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        double a = 0.0;
+        for (int i = lo; i < hi; ++i) a += (double)Xc[((size_t)s * n + members[(size_t)s * n + i]) * D + d];
+        sums[((size_t)s * k + c) * D + d] = a;
+    }
+}
+
+// _relocate_empty_clusters_dense (_k_means_common.pyx:167-211), one workgroup per slide; rare path
+__global__ __launch_bounds__(KM_THREADS) void km_relocate_kernel(const float* __restrict__ Xc, const float* __restrict__ centers,
+                                                                 const int* __restrict__ labels, int* __restrict__ offsets,
+                                                                 double* __restrict__ sums, double* __restrict__ weights,
+                                                                 double* __restrict__ dist_ws, const KmState* __restrict__ st,
+                                                                 int n, int D, int k) {
+    __shared__ int empty[KM_MAX_K];
+    __shared__ int n_empty;
+    __shared__ int far_idx;
+    const int s = blockIdx.x;
+    if (st[s].done) return;
+    const int* off = offsets + (size_t)s * (k + 1);
+    double* w = weights + (size_t)s * k;
+    for (int c = threadIdx.x; c < k; c += blockDim.x) w[c] = (double)(off[c + 1] - off[c]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int e = 0;
+        for (int c = 0; c < k; ++c)
+            if (w[c] == 0.0) empty[e++] = c;
+        n_empty = e;
+    }
+    __syncthreads();
+    if (n_empty == 0) return;
+    // distances of every point to its (old) centre: ((X - centers_old[labels])**2).sum(axis=1)
+    double* dist = dist_ws + (size_t)s * n;
+    for (int j = threadIdx.x >> 6; j < n; j += blockDim.x >> 6) {
+        const float* xr = Xc + ((size_t)s * n + j) * D;
+        const float* cr = centers + ((size_t)s * k + labels[(size_t)s * n + j]) * D;
+        double a = 0.0;
+        for (int d = threadIdx.x & 63; d < D; d += 64) { const float t = xr[d] - cr[d]; a += (double)(t * t); }
+        a = wave_sum_f64(a);
+        if ((threadIdx.x & 63) == 0) dist[j] = a;
+    }
+    __syncthreads();
+    for (int e = 0; e < n_empty; ++e) {
+        if (threadIdx.x == 0) {          // farthest remaining point (descending distance, ties by index)
+            int bi = -1; double bd = -1.0;
+            for (int j = 0; j < n; ++j)
+                if (dist[j] > bd) { bd = dist[j]; bi = j; }
+            far_idx = bd > 0.0 ? bi : -1;
+            if (bi >= 0) dist[bi] = -2.0;
+        }
+        __syncthreads();
+        const int fi = far_idx;
+        if (fi < 0) break;               // np.max(distances) == 0: relocation is pointless
+        const int new_id = empty[e], old_id = labels[(size_t)s * n + fi];
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            const double x = (double)Xc[((size_t)s * n + fi) * D + d];
+            sums[((size_t)s * k + old_id) * D + d] -= x;
+            sums[((size_t)s * k + new_id) * D + d] = x;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { w[new_id] = 1.0; w[old_id] -= 1.0; }
+        __syncthreads();
+    }
+}
+
+// _average_centers + _center_shift + the stop rule of _kmeans_single_lloyd; one workgroup per slide
+__global__ __launch_bounds__(KM_THREADS) void km_update_kernel(float* __restrict__ centers, const double* __restrict__ sums,
+                                                               const double* __restrict__ weights, const int* __restrict__ labels,
+                                                               int* __restrict__ labels_old, KmState* __restrict__ st, int n,
+                                                               int D, int k, int max_iter) {
+    __shared__ double sh[16];
+    __shared__ int shi[16];
+    __shared__ int amax;
+    const int s = blockIdx.x;
+    if (st[s].done) return;
+    const double* w = weights + (size_t)s * k;
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int c = 1; c < k; ++c)
+            if (w[c] > w[a]) a = c;      // np.argmax: first maximum
+        amax = a;
+    }
+    __syncthreads();
+    double shift = 0.0;
+    for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
+        const int c = i / D, d = i - c * D;
+        const int src = w[c] > 0.0 ? c : amax;
+        const float nv = (float)(sums[((size_t)s * k + src) * D + d] / w[src]);
+        const float ov = centers[(size_t)s * k * D + i];
+        const double df = (double)nv - (double)ov;
+        shift += df * df;
+    }
+    shift = block_reduce_sum(shift, sh);
+    __syncthreads();
+    // write after every thread has read the old centres of the rows it needs (amax row is read by others)
+    for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
+        const int c = i / D, d = i - c * D;
+        const int src = w[c] > 0.0 ? c : amax;
+        centers[(size_t)s * k * D + i] = (float)(sums[((size_t)s * k + src) * D + d] / w[src]);
+    }
+    int diff = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const int l = labels[(size_t)s * n + j];
+        diff += l != labels_old[(size_t)s * n + j];
+        labels_old[(size_t)s * n + j] = l;
+    }
+    diff = block_reduce_sum_int(diff, shi);
+    if (threadIdx.x == 0) {
+        KmState& ks = st[s];
+        ks.iter += 1;
+        ks.shift = shift;
+        if (diff == 0) { ks.strict = 1; ks.done = 1; }
+        else if (shift <= ks.tol) ks.done = 1;
+        else if (ks.iter >= max_iter) ks.done = 1;
+    }
+}
+
+__global__ void km_restore_strict_kernel(int* __restrict__ labels, const int* __restrict__ labels_old, const KmState* __restrict__ st, int n) {
+    const int s = blockIdx.y;
+    if (!st[s].strict) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) labels[(size_t)s * n + j] = labels_old[(size_t)s * n + j];
+}
+
+__global__ void km_count_done_kernel(const KmState* __restrict__ st, int S, int* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int d = 0;
+        for (int s = 0; s < S; ++s) d += st[s].done;
+        *out = d;
+    }
+}
+
+__global__ void km_report_kernel(const KmState* __restrict__ st, int S, int* __restrict__ n_iter) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S && n_iter) n_iter[s] = st[s].iter;
+}
+
+// kmean_features.py:99-105: np.mean(features[labels == c], axis=0): fp32 adds in index order, / count
+__global__ void km_cluster_means_kernel(const float* __restrict__ X, const int* __restrict__ members, const int* __restrict__ offsets,
+                                        float* __restrict__ out, int n, int D, int k) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int lo = offsets[(size_t)s * (k + 1) + c], hi = offsets[(size_t)s * (k + 1) + c + 1];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float a = 0.f;
+        for (int i = lo; i < hi; ++i) a += X[((size_t)s * n + members[(size_t)s * n + i]) * D + d];
+        out[((size_t)s * k + c) * D + d] = a / (float)(hi - lo);      // empty cluster -> 0/0 = NaN like numpy
+    }
+}
+
+struct KmBufs {
+    float* Xc; double* colvar; double* G; float* centers; double* dots; double* sums; double* weights; double* dist;
+    int* seeds; int* labels_old; int* members; int* offsets; int* done_count; KmState* st;
+    size_t bytes;
+};
+
+void km_bufs(int S, int n, int D, int k, char* base, KmBufs* o) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = sq_align_up(off, 256); char* p = base ? base + off : nullptr; off += bytes; return (void*)p; };
+    o->Xc = (float*)take((size_t)S * n * D * 4);
+    o->colvar = (double*)take((size_t)S * D * 8);
+    o->G = (double*)take((size_t)S * n * n * 8);
+    o->centers = (float*)take((size_t)S * k * D * 4);
+    o->dots = (double*)take((size_t)S * n * k * 8);
+    o->sums = (double*)take((size_t)S * k * D * 8);
+    o->weights = (double*)take((size_t)S * k * 8);
+    o->dist = (double*)take((size_t)S * n * 8);
+    o->seeds = (int*)take((size_t)S * k * 4);
+    o->labels_old = (int*)take((size_t)S * n * 4);
+    o->members = (int*)take((size_t)S * n * 4);
+    o->offsets = (int*)take((size_t)S * (k + 1) * 4);
+    o->done_count = (int*)take(256);
+    o->st = (KmState*)take((size_t)S * sizeof(KmState));
+    o->bytes = sq_align_up(off, 256);
+}
+
+}  // namespace
+
+extern "C" size_t sq_kmeans_workspace_bytes(int n_slides, int n_samples, int dim, int n_clusters) {
+    if (n_slides < 1 || n_samples < 1 || dim < 1 || n_clusters < 1) return 0;
+    KmBufs b;
+    km_bufs(n_slides, n_samples, dim, n_clusters, nullptr, &b);
+    return b.bytes;
+}
+
+extern "C" int sq_kmeans_fit(const float* X, int S, int n, int D, int k, int first_center, const double* uniforms,
+                             int n_local_trials, int max_iter, double tol, int32_t* labels, float* cluster_features,
+                             int32_t* seed_indices, int32_t* n_iter, void* workspace, size_t workspace_bytes,
+                             sq_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SQ_REQUIRE(X && labels && uniforms && workspace, "kmeans: null pointer");
+    SQ_REQUIRE(S >= 1 && n >= k && k >= 1 && k <= KM_MAX_K, "kmeans: need n_samples >= n_clusters and 1 <= n_clusters <= %d (n=%d k=%d)", KM_MAX_K, n, k);
+    SQ_REQUIRE(n <= 4096, "kmeans: n_samples=%d > 4096 per slide (max_patch_number default is 4000)", n);
+    SQ_REQUIRE(D % 4 == 0, "kmeans: dim=%d must be a multiple of 4", D);
+    SQ_REQUIRE(n_local_trials >= 1 && n_local_trials <= KM_MAX_TRIALS, "kmeans: n_local_trials=%d", n_local_trials);
+    SQ_REQUIRE(first_center >= 0 && first_center < n, "kmeans: first_center=%d", first_center);
+    KmBufs b;
+    km_bufs(S, n, D, k, (char*)workspace, &b);
+    if (b.bytes > workspace_bytes) {
+        sq_set_error("kmeans: workspace %zu < required %zu", workspace_bytes, b.bytes);
+        return SQ_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(km_center_kernel, dim3((D + 255) / 256, S), dim3(256), 0, st, X, b.Xc, b.colvar, n, D);
+    SQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(km_tol_kernel, dim3(S), dim3(256), 0, st, b.colvar, b.st, D, tol);
+    SQ_LAUNCH_CHECK();
+    // Gram matrix of the centred data (fp64)
+    hipLaunchKernelGGL(km_dgemm_nt_kernel, dim3((n + 63) / 64, (n + 63) / 64, S), dim3(256), 0, st, b.Xc, b.Xc, b.G, n, n, D,
+                       (long long)n * D, (long long)n * D, (long long)n * n);
+    SQ_LAUNCH_CHECK();
+    if (n <= KM_THREADS)
+        hipLaunchKernelGGL(km_seed_kernel<1>, dim3(S), dim3(KM_THREADS), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
+    else if (n <= 2 * KM_THREADS)
+        hipLaunchKernelGGL(km_seed_kernel<2>, dim3(S), dim3(KM_THREADS), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
+    else
+        hipLaunchKernelGGL(km_seed_kernel<4>, dim3(S), dim3(KM_THREADS), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
+    SQ_LAUNCH_CHECK();
+    if (seed_indices) SQ_HIP_CHECK(hipMemcpyAsync(seed_indices, b.seeds, (size_t)S * k * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(km_gather_centers_kernel, dim3(k, S), dim3(256), 0, st, b.Xc, b.seeds, b.centers, n, D, k);
+    SQ_LAUNCH_CHECK();
+    SQ_HIP_CHECK(hipMemsetAsync(b.labels_old, 0xff, (size_t)S * n * 4, st));          // labels_old = -1
+
+    auto e_step = [&](int force) -> int {
+        hipLaunchKernelGGL(km_dgemm_nt_kernel, dim3((k + 63) / 64, (n + 63) / 64, S), dim3(256), 0, st, b.Xc, b.centers, b.dots, n, k, D,
+                           (long long)n * D, (long long)k * D, (long long)n * k);
+        SQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(km_assign_kernel, dim3((n + 255) / 256, S), dim3(256), 0, st, b.dots, b.centers, labels, b.st, n, D, k, force);
+        SQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(km_members_kernel, dim3(S), dim3(KM_THREADS), 0, st, labels, b.members, b.offsets, b.st, n, k, force);
+        SQ_LAUNCH_CHECK();
+        return SQ_OK;
+    };
+    int it = 0;
+    while (it < max_iter) {
+        const int burst = it == 0 ? 3 : 4;      // iterations between host checks of the done flags
+        for (int q = 0; q < burst && it < max_iter; ++q, ++it) {
+            if (int e = e_step(0)) return e;
+            hipLaunchKernelGGL(km_sums_kernel, dim3(k, S), dim3(256), 0, st, b.Xc, b.members, b.offsets, b.sums, b.st, n, D, k);
+            SQ_LAUNCH_CHECK();
+            hipLaunchKernelGGL(km_relocate_kernel, dim3(S), dim3(KM_THREADS), 0, st, b.Xc, b.centers, labels, b.offsets, b.sums,
+                               b.weights, b.dist, b.st, n, D, k);
+            SQ_LAUNCH_CHECK();
+            hipLaunchKernelGGL(km_update_kernel, dim3(S), dim3(KM_THREADS), 0, st, b.centers, b.sums, b.weights, labels, b.labels_old,
+                               b.st, n, D, k, max_iter);
+            SQ_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(km_count_done_kernel, dim3(1), dim3(64), 0, st, b.st, S, b.done_count);
+        SQ_LAUNCH_CHECK();
+        int done = 0;
+        SQ_HIP_CHECK(hipMemcpyAsync(&done, b.done_count, 4, hipMemcpyDeviceToHost, st));
+        SQ_HIP_CHECK(hipStreamSynchronize(st));
+        if (done == S) break;
+    }
+    // final E-step for the slides that did not converge strictly (labels must match the final centres).
+    // For strictly converged slides the labels of the last E-step are already the answer and the
+    // centres moved by a label-preserving update, so re-running the E-step for everyone is only
+    // correct for the non-strict ones: the assign kernel is forced, then strict slides are restored.
+    {
+        // strict slides keep labels (== labels_old after the last update); non-strict get a fresh E-step
+        if (int e = e_step(1)) return e;
+        // restore labels of strict slides from labels_old and rebuild their member lists
+        hipLaunchKernelGGL(km_restore_strict_kernel, dim3((n + 255) / 256, S), dim3(256), 0, st, labels, (const int*)b.labels_old, (const KmState*)b.st, n);
+        SQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(km_members_kernel, dim3(S), dim3(KM_THREADS), 0, st, labels, b.members, b.offsets, b.st, n, k, 1);
+        SQ_LAUNCH_CHECK();
+    }
+    if (cluster_features) {
+        hipLaunchKernelGGL(km_cluster_means_kernel, dim3(k, S), dim3(256), 0, st, X, b.members, b.offsets, cluster_features, n, D, k);
+        SQ_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(km_report_kernel, dim3((S + 63) / 64), dim3(64), 0, st, b.st, S, n_iter);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}

@@ -34,6 +34,7 @@ struct VisBufs {
     void* Y[SQ_MAX_DEPTH];              // [M, D] T     LayerNorm(X1)
     float* U[SQ_MAX_DEPTH];             // [M, D] f32   FF pre-activation (saved only when training)
     void* H1[SQ_MAX_DEPTH];             // [M, D] T     GELU(U)
+    float* skws; size_t skws_bytes;     // split-K scratch for the skinny (M = B) GEMMs
     float* xm;                          // [B, D] f32 token mean of the last layer output
     void* xn;                           // [B, D] T   LayerNorm(xm)
     size_t bytes;

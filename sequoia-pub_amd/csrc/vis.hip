@@ -57,6 +57,8 @@ void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base,
             o->P[l] = o->P[0]; o->O[l] = o->O[0]; o->Y[l] = o->Y[0]; o->U[l] = o->U[0]; o->H1[l] = o->H1[0];
         }
     }
+    o->skws_bytes = (size_t)16 * B * (HD > D ? HD : D) * 4;
+    o->skws = (float*)a.take(o->skws_bytes);
     o->xm = (float*)a.take((size_t)B * D * 4);
     o->xn = a.take((size_t)B * D * es);
     o->bytes = sq_align_up(a.off, 256);
@@ -161,7 +163,7 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
         {   // Sm = Xbar Ws^T + bs
             GemmArgs g; g.A = w.Xbar[s]; g.lda = D; g.a_bytes = (size_t)B * D * es;
             g.B = W(L.s_w); g.ldb = D; g.b_bytes = Wrem(L.s_w); g.bias = Pf(L.s_b);
-            g.C = w.Sm[s]; g.ldc = HD; g.M = B; g.N = HD; g.K = D;
+            g.C = w.Sm[s]; g.ldc = HD; g.M = B; g.N = HD; g.K = D; g.splitk_ws = w.skws; g.splitk_ws_bytes = w.skws_bytes;
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
         if (int e = sq_k_ln64_gelu(w.Sm[s], Pf(L.lns_g), Pf(L.lns_b), w.Ts[s], dtype, B, HD, st)) return e;
@@ -221,7 +223,8 @@ extern "C" int sq_cast_f32_to_bf16(const float* src, void* dst, size_t n, sq_str
 }
 
 extern "C" int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual,
-                         int ldres, int act, void* C, int out_dtype, int ldc, int M, int N, int K, sq_stream_t stream) {
+                         int ldres, int act, void* C, int out_dtype, int ldc, int M, int N, int K, void* workspace,
+                         size_t workspace_bytes, sq_stream_t stream) {
     SQ_REQUIRE(A && W && C, "linear: null pointer");
     SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16, "linear: dtype %d", dtype);
     GemmArgs g;
@@ -230,5 +233,6 @@ extern "C" int sq_linear(int dtype, const void* A, int lda, const void* W, int l
     g.B = W; g.ldb = ldw; g.b_bytes = ((size_t)(N - 1) * ldw + K) * es;
     g.bias = bias; g.res = residual; g.ldres = ldres; g.act = act;
     g.C = C; g.out_dtype = out_dtype; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.splitk_ws = (float*)workspace; g.splitk_ws_bytes = workspace_bytes;
     return sq_launch_gemm(g, dtype, (hipStream_t)stream);
 }

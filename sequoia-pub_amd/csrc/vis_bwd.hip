@@ -29,6 +29,7 @@ struct BwdBufs {
     void* whT;                       // [D, Gp] T
     float* dxn; float* dxm;          // [B, D]
     float* red_ws;                   // reduction scratch
+    float* skws; size_t skws_bytes;  // split-K scratch (dW products have K = tokens and few output tiles)
     size_t bytes;
 };
 
@@ -62,6 +63,8 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
     const size_t cs = sq_colsum_ws_floats((int)(G > W ? G : W));
     if (cs > red) red = cs;
     o->red_ws = (float*)a.take(red * 4);
+    o->skws_bytes = (size_t)16 * W * W * 4;
+    o->skws = (float*)a.take(o->skws_bytes);
     o->bytes = sq_align_up(a.off, 256);
 }
 
@@ -110,6 +113,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         g.A = A; g.lda = lda; g.a_bytes = ((size_t)(M_ - 1) * lda + K_) * es;
         g.B = Bm; g.ldb = ldb; g.b_bytes = ((size_t)(N_ - 1) * ldb + K_) * es;
         g.C = C; g.ldc = ldc; g.M = M_; g.N = N_; g.K = K_;
+        g.splitk_ws = b.skws; g.splitk_ws_bytes = b.skws_bytes;
         return g;
     };
     auto tr = [&](const void* src, int lds_, void* dst, int ldd, int R, int C) {

@@ -16,7 +16,7 @@ SHAPES = [(128, 128, 64), (200, 136, 96), (64, 20820 // 10, 128), (6400, 1024, 1
           (1000, 64, 256), (300, 520, 1032), (129, 65, 40)]
 
 
-def run_linear(dtype, A, W, bias, res, act, out_bf16=False):
+def run_linear(dtype, A, W, bias, res, act, out_bf16=False, ws_bytes=0):
     dev = "cuda"
     M, K = A.shape
     N = W.shape[0]
@@ -25,9 +25,10 @@ def run_linear(dtype, A, W, bias, res, act, out_bf16=False):
     bd = bias.to(dev) if bias is not None else None
     rd = res.to(dev) if res is not None else None
     C = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     _lib.check(_lib.lib().sq_linear(dtype, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(bd), _lib.ptr(rd), N, act,
                                     _lib.ptr(C), _lib.SQ_BF16 if out_bf16 else _lib.SQ_F32, N, M, N, K,
-                                    _lib.stream_ptr()))
+                                    _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
     torch.cuda.synchronize()
     return C.float().cpu()
 
@@ -74,9 +75,26 @@ def test_linear_bf16_mfma(M, N, K):
     assert rel_err(out16, torch.relu(ref)) < 5e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (1024, 1024, 6400), (64, 128, 20824), (200, 520, 4104)])
+@pytest.mark.parametrize("dtype", [_lib.SQ_F32, _lib.SQ_BF16])
+def test_split_k_path(M, N, K, dtype):
+    """skinny problems with a workspace take the deterministic split-K path (same epilogue)."""
+    _lib.require_gpu()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = to_bf16_f32(torch.randn(M, K, generator=g))
+    W = to_bf16_f32(torch.randn(N, K, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    out = run_linear(dtype, A, W, bias, res, 1, ws_bytes=64 << 20)
+    out2 = run_linear(dtype, A, W, bias, res, 1, ws_bytes=64 << 20)
+    ref = ref_linear(A, W, bias, res, 1)
+    assert rel_err(out, ref) < 1e-5, rel_err(out, ref)
+    assert torch.equal(out, out2)                      # fixed reduction order -> bitwise repeatable
+
+
 def test_bad_arguments_fail_loudly():
     _lib.require_gpu()
     A = torch.zeros(4, 6, device="cuda")
     rc = _lib.lib().sq_linear(_lib.SQ_F32, _lib.ptr(A), 6, _lib.ptr(A), 6, None, None, 0, 0, _lib.ptr(A), 0, 4, 4, 4, 6,
-                              _lib.stream_ptr())
+                              None, 0, _lib.stream_ptr())
     assert rc != 0 and b"multiple" in _lib.lib().sq_last_error()
