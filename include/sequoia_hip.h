@@ -134,6 +134,32 @@ int sq_kmeans_fit(const float* X, int n_slides, int n_samples, int dim, int n_cl
                   float* cluster_features, int32_t* seed_indices, int32_t* n_iter, void* workspace,
                   size_t workspace_bytes, sq_stream_t stream);
 
+/* ------------------------------------------------------------------------------
+ * ResNet-50 patch embedding  (src/resnet.py:155-170 forward_extract; :73-93 Bottleneck;
+ * :98-136 topology; eval-mode BN; patch transform pre_processing/compute_features_hdf5.py:49-51,119-120)
+ * Weights are packed by the caller per sq_resnet50_layout: conv i at w_off (elements) as
+ * [cout][kh][kw][cin] (conv 0: K = 147 zero-padded to k_padded = 152) with eval-mode BatchNorm
+ * folded in, bias (fp32) at b_off.  Conv order: conv1; then per bottleneck conv1, conv2, conv3,
+ * [downsample.0 for the first block of each layer].
+ * sq_resnet50_extract: give EITHER patches_u8 (uint8 NHWC [n, S, S, 3]: /255 and ImageNet
+ * normalisation fused) OR patches_f32_nchw (fp32 [n, 3, S, S], already normalised: the tensor the
+ * reference feeds forward_extract).  features: f32 [n, 2048].  S in {224, 256, ...}, multiple of 32.
+ * ---------------------------------------------------------------------------- */
+#define SQ_RESNET50_CONVS 53
+typedef struct sq_conv_desc {
+    int64_t w_off, b_off;
+    int32_t cin, cout, k, stride, pad, k_padded;
+} sq_conv_desc;
+typedef struct sq_resnet50_layout {
+    sq_conv_desc conv[SQ_RESNET50_CONVS];
+    int64_t w_total, b_total;
+} sq_resnet50_layout;
+int sq_resnet50_layout_init(sq_resnet50_layout* out);
+size_t sq_resnet50_workspace_bytes(int dtype, int n_patches, int patch_size);
+int sq_resnet50_extract(int dtype, const void* weights, const float* bias, const uint8_t* patches_u8,
+                        const float* patches_f32_nchw, int n_patches, int patch_size, float* features,
+                        void* workspace, size_t workspace_bytes, sq_stream_t stream);
+
 /* dst_bf16[i] = bf16(src[i]) -- refresh of the bf16 parameter shadow after an optimizer step */
 int sq_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, sq_stream_t stream);
 

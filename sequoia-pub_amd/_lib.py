@@ -40,6 +40,15 @@ class VisLayout(ctypes.Structure):
                 ("layer", VisLayerOffsets * SQ_MAX_DEPTH)]
 
 
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32),
+                ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("k_padded", ctypes.c_int32)]
+
+
+class ResNet50Layout(ctypes.Structure):
+    _fields_ = [("conv", ConvDesc * 53), ("w_total", ctypes.c_int64), ("b_total", ctypes.c_int64)]
+
+
 class SequoiaHipError(RuntimeError):
     pass
 
@@ -76,6 +85,12 @@ def _declare(lib):
     lib.sq_kmeans_workspace_bytes.argtypes = [i32, i32, i32, i32]
     lib.sq_kmeans_fit.restype = i32
     lib.sq_kmeans_fit.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, i32, ctypes.c_double, vp, vp, vp, vp, vp, sz, vp]
+    lib.sq_resnet50_layout_init.restype = i32
+    lib.sq_resnet50_layout_init.argtypes = [ctypes.POINTER(ResNet50Layout)]
+    lib.sq_resnet50_workspace_bytes.restype = sz
+    lib.sq_resnet50_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.sq_resnet50_extract.restype = i32
+    lib.sq_resnet50_extract.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.sq_prof_enable.restype = i32
     lib.sq_prof_enable.argtypes = [i32]
     lib.sq_prof_report.restype = i32

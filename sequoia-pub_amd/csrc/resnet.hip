@@ -1,0 +1,264 @@
+// ResNet-50 patch embedding (forward_extract) on the MFMA GEMM engine.
+//
+// Stands behind src/resnet.py:155-170 (forward_extract), :73-93 (Bottleneck.forward, stride on the 3x3),
+// :98-136 (topology [3,4,6,3]) in eval mode, and the patch transform of
+// pre_processing/compute_features_hdf5.py:49-51,119-120 (uint8 HWC -> /255 -> ImageNet normalise).
+//
+// Layout: activations NHWC (channels contiguous = the GEMM K axis), weights [Cout][kh][kw][Cin] with
+// eval-mode BatchNorm folded in (w' = w * g/sqrt(var+eps), b' = beta - mean * g/sqrt(var+eps); folded on
+// the host in fp64).  Every convolution is one launch of the NT GEMM engine:
+//   1x1 stride 1        plain GEMM on [n*H*W, Cin]
+//   3x3 / 1x1 stride 2  implicit GEMM (the A-tile loader gathers the taps, zero padding via buffer OOB)
+//   conv1 7x7 (Cin = 3) explicit im2col (K = 147 padded to 152) fused with the uint8 -> normalised cast
+// with bias + residual + ReLU in the GEMM epilogue.  Max-pool and the final 7x7 average are small
+// memory-bound kernels.
+#include "../../include/sequoia_hip.h"
+#include "gemm.h"
+
+namespace {
+
+constexpr int CONV1_K = 147, CONV1_KP = 152;
+constexpr float BN_MEAN[3] = {0.485f, 0.456f, 0.406f};
+constexpr float BN_STD[3] = {0.229f, 0.224f, 0.225f};
+
+// A0[m, k] for conv1: m = (img, oh, ow), k = (kh*7 + kw)*3 + c; zero for padding taps and k >= 147.
+// src_u8: uint8 NHWC (transform fused) or src_f32: fp32 NCHW (already normalised, reference tensor layout)
+template <typename T>
+__global__ void im2col_conv1_kernel(const uint8_t* __restrict__ src_u8, const float* __restrict__ src_f32, T* __restrict__ out,
+                                    int n, int S, int OH) {
+    const size_t total = (size_t)n * OH * OH * (CONV1_KP / 8);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % (CONV1_KP / 8));
+        const size_t m = idx / (CONV1_KP / 8);
+        const int ow = (int)(m % OH), oh = (int)((m / OH) % OH), img = (int)(m / ((size_t)OH * OH));
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            float x = 0.f;
+            if (k < CONV1_K) {
+                const int tap = k / 3, c = k - tap * 3;
+                const int kh = tap / 7, kw = tap - kh * 7;
+                const int ih = oh * 2 - 3 + kh, iw = ow * 2 - 3 + kw;
+                if ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) {
+                    if (src_u8) {
+                        // ConvertImageDtype(float): u8 / 255 ; Normalize: (x - mean) / std, all fp32
+                        const float p = (float)src_u8[(((size_t)img * S + ih) * S + iw) * 3 + c] / 255.0f;
+                        x = (p - BN_MEAN[c]) / BN_STD[c];
+                    } else {
+                        x = src_f32[(((size_t)img * 3 + c) * S + ih) * S + iw];
+                    }
+                }
+            }
+            v[e] = x;
+        }
+        if constexpr (sizeof(T) == 2) {
+            u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            *reinterpret_cast<u32x4*>(out + m * CONV1_KP + ch * 8) = o;
+        } else {
+            f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4*>(out + m * CONV1_KP + ch * 8) = a;
+            *reinterpret_cast<f32x4*>(out + m * CONV1_KP + ch * 8 + 4) = b;
+        }
+    }
+}
+
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// MaxPool2d(3, stride 2, padding 1) on NHWC (resnet.py:105); thread = (pixel, channel)
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int n, int H, int OH, int C) {
+    const size_t total = (size_t)n * OH * OH * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const size_t px = idx / C;
+        const int ow = (int)(px % OH), oh = (int)((px / OH) % OH), img = (int)(px / ((size_t)OH * OH));
+        float best = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)H)
+                    best = fmaxf(best, ldf(in + (((size_t)img * H + ih) * H + iw) * C + c));
+            }
+        stf(out + idx, best);
+    }
+}
+
+// AvgPool2d(7) (resnet.py:110,166): mean of the top-left 7x7 window of the final map, fp32 out
+template <typename T>
+__global__ void avgpool7_kernel(const T* __restrict__ in, float* __restrict__ out, int n, int H, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * C) return;
+    const int c = idx % C, img = idx / C;
+    float acc = 0.f;
+    for (int h = 0; h < 7; ++h)
+        for (int w = 0; w < 7; ++w) acc += ldf(in + (((size_t)img * H + h) * H + w) * C + c);
+    out[idx] = acc / 49.0f;
+}
+
+struct ConvSpec { int cin, cout, k, stride, pad; };
+
+void build_specs(ConvSpec* specs) {
+    int i = 0;
+    specs[i++] = {3, 64, 7, 2, 3};
+    const int planes[4] = {64, 128, 256, 512}, blocks[4] = {3, 4, 6, 3};
+    int inplanes = 64;
+    for (int li = 0; li < 4; ++li)
+        for (int b = 0; b < blocks[li]; ++b) {
+            const int s = (b == 0 && li > 0) ? 2 : 1;
+            specs[i++] = {inplanes, planes[li], 1, 1, 0};
+            specs[i++] = {planes[li], planes[li], 3, s, 1};
+            specs[i++] = {planes[li], planes[li] * 4, 1, 1, 0};
+            if (b == 0) specs[i++] = {inplanes, planes[li] * 4, 1, s, 0};
+            inplanes = planes[li] * 4;
+        }
+}
+
+struct RnBufs { void* col; void* act[5]; size_t bytes; };
+
+void rn_bufs(int dtype, int n, int S, char* base, RnBufs* o) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = sq_align_up(off, 256); char* p = base ? base + off : nullptr; off += bytes; return (void*)p; };
+    const size_t es = sq_dtype_size(dtype);
+    const size_t OH = S / 2;
+    o->col = take((size_t)n * OH * OH * CONV1_KP * es);
+    const size_t act = (size_t)n * OH * OH * 64 * es;          // largest activation: conv1 out == layer1 out
+    for (int i = 0; i < 5; ++i) o->act[i] = take(act);
+    o->bytes = sq_align_up(off, 256);
+}
+
+}  // namespace
+
+extern "C" int sq_resnet50_layout_init(sq_resnet50_layout* out) {
+    SQ_REQUIRE(out != nullptr, "resnet50_layout: null");
+    ConvSpec specs[SQ_RESNET50_CONVS];
+    build_specs(specs);
+    int64_t w = 0, b = 0;
+    for (int i = 0; i < SQ_RESNET50_CONVS; ++i) {
+        sq_conv_desc& d = out->conv[i];
+        d.cin = specs[i].cin; d.cout = specs[i].cout; d.k = specs[i].k; d.stride = specs[i].stride; d.pad = specs[i].pad;
+        d.k_padded = i == 0 ? CONV1_KP : specs[i].k * specs[i].k * specs[i].cin;
+        d.w_off = w; d.b_off = b;
+        w += (int64_t)d.cout * d.k_padded;
+        b += d.cout;
+        w = (w + 7) / 8 * 8;
+        b = (b + 7) / 8 * 8;
+    }
+    out->w_total = w;
+    out->b_total = b;
+    return SQ_OK;
+}
+
+extern "C" size_t sq_resnet50_workspace_bytes(int dtype, int n_patches, int patch_size) {
+    if (n_patches < 1 || patch_size < 32 || patch_size % 32) return 0;
+    RnBufs b;
+    rn_bufs(dtype, n_patches, patch_size, nullptr, &b);
+    return b.bytes;
+}
+
+extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* bias, const uint8_t* patches_u8,
+                                   const float* patches_f32_nchw, int n, int S, float* features, void* workspace,
+                                   size_t workspace_bytes, sq_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16, "resnet50: dtype %d", dtype);
+    SQ_REQUIRE(weights && bias && features && workspace, "resnet50: null pointer");
+    SQ_REQUIRE((patches_u8 != nullptr) != (patches_f32_nchw != nullptr), "resnet50: give exactly one of patches_u8 / patches_f32_nchw");
+    SQ_REQUIRE(n >= 1 && S >= 224 && S % 32 == 0, "resnet50: n=%d patch_size=%d (need a multiple of 32, >= 224)", n, S);
+    sq_resnet50_layout lay;
+    sq_resnet50_layout_init(&lay);
+    RnBufs b;
+    rn_bufs(dtype, n, S, (char*)workspace, &b);
+    if (b.bytes > workspace_bytes) {
+        sq_set_error("resnet50: workspace %zu < required %zu", workspace_bytes, b.bytes);
+        return SQ_ERR_WORKSPACE;
+    }
+    const size_t es = sq_dtype_size(dtype);
+    const bool lp = dtype == SQ_BF16;
+    auto W = [&](const sq_conv_desc& d) { return (const void*)((const char*)weights + (size_t)d.w_off * es); };
+    const size_t w_bytes_total = (size_t)lay.w_total * es;
+    const size_t act_cap = (size_t)n * (S / 2) * (S / 2) * 64 * es;
+    SQ_REQUIRE(act_cap < (1ull << 31) && (size_t)n * (S / 2) * (S / 2) * CONV1_KP * es < (1ull << 31),
+               "resnet50: sub-batch of %d patches exceeds the 2 GiB buffer-descriptor limit; use <= 256", n);
+
+    // conv as a GEMM launch.  in: NHWC [n, H, H, cin];  out: [n, OH, OH, cout]
+    auto conv = [&](const sq_conv_desc& d, const void* in, int H, void* out, int OH, const void* res, int act) -> int {
+        GemmArgs g;
+        g.M = n * OH * OH; g.N = d.cout; g.K = d.k_padded;
+        g.A = in;
+        if (d.k == 1 && d.stride == 1) {
+            g.lda = d.cin; g.a_bytes = (size_t)g.M * d.cin * es;
+        } else {
+            g.conv = 1; g.H = H; g.W = H; g.Cin = d.cin; g.OH = OH; g.OW = OH; g.KW = d.k; g.stride = d.stride; g.pad = d.pad;
+            g.a_bytes = (size_t)n * H * H * d.cin * es;
+        }
+        g.B = W(d); g.ldb = d.k_padded; g.b_bytes = w_bytes_total - (size_t)d.w_off * es;
+        g.bias = bias + d.b_off;
+        g.res = res; g.ldres = d.cout; g.res_dtype = dtype;
+        g.act = act;
+        g.C = out; g.ldc = d.cout; g.out_dtype = dtype;
+        return sq_launch_gemm(g, dtype, st);
+    };
+#define RUN(expr) do { if (int _e = (expr)) return _e; } while (0)
+
+    const int OH1 = S / 2;
+    {   // conv1 + bn1 + relu
+        const size_t work = (size_t)n * OH1 * OH1 * (CONV1_KP / 8);
+        size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
+        if (lp) hipLaunchKernelGGL(im2col_conv1_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (bf16_t*)b.col, n, S, OH1);
+        else hipLaunchKernelGGL(im2col_conv1_kernel<float>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (float*)b.col, n, S, OH1);
+        SQ_LAUNCH_CHECK();
+        GemmArgs g;
+        const sq_conv_desc& d = lay.conv[0];
+        g.M = n * OH1 * OH1; g.N = 64; g.K = CONV1_KP;
+        g.A = b.col; g.lda = CONV1_KP; g.a_bytes = (size_t)g.M * CONV1_KP * es;
+        g.B = W(d); g.ldb = CONV1_KP; g.b_bytes = w_bytes_total;
+        g.bias = bias + d.b_off; g.act = SQ_ACT_RELU;
+        g.C = b.act[0]; g.ldc = 64; g.out_dtype = dtype;
+        RUN(sq_launch_gemm(g, dtype, st));
+    }
+    int H = OH1 / 2;    // after the max-pool
+    {
+        const size_t work = (size_t)n * H * H * 64;
+        size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
+        if (lp) hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, st, (const bf16_t*)b.act[0], (bf16_t*)b.act[1], n, OH1, H, 64);
+        else hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3((int)nb), dim3(256), 0, st, (const float*)b.act[0], (float*)b.act[1], n, OH1, H, 64);
+        SQ_LAUNCH_CHECK();
+    }
+    // bottleneck stack: x lives in act[xi]; t1, t2, ds, y are the other four buffers
+    int xi = 1, ci = 1;
+    const int blocks[4] = {3, 4, 6, 3};
+    for (int li = 0; li < 4; ++li)
+        for (int bk = 0; bk < blocks[li]; ++bk) {
+            int free_[4], nf = 0;
+            for (int i = 0; i < 5; ++i) if (i != xi) free_[nf++] = i;
+            void* x = b.act[xi]; void* t1 = b.act[free_[0]]; void* t2 = b.act[free_[1]]; void* ds = b.act[free_[2]]; void* y = b.act[free_[3]];
+            const sq_conv_desc& c1 = lay.conv[ci]; const sq_conv_desc& c2 = lay.conv[ci + 1]; const sq_conv_desc& c3 = lay.conv[ci + 2];
+            const bool has_ds = bk == 0;
+            const int OH = H / c2.stride;
+            RUN(conv(c1, x, H, t1, H, nullptr, SQ_ACT_RELU));
+            RUN(conv(c2, t1, H, t2, OH, nullptr, SQ_ACT_RELU));
+            const void* identity = x;
+            if (has_ds) {
+                RUN(conv(lay.conv[ci + 3], x, H, ds, OH, nullptr, SQ_ACT_NONE));
+                identity = ds;
+            }
+            RUN(conv(c3, t2, OH, y, OH, identity, SQ_ACT_RELU));       // relu(bn3(conv3) + identity)
+            ci += has_ds ? 4 : 3;
+            xi = free_[3];
+            H = OH;
+        }
+    {
+        const int total = n * 2048;
+        if (lp) hipLaunchKernelGGL(avgpool7_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], features, n, H, 2048);
+        else hipLaunchKernelGGL(avgpool7_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)b.act[xi], features, n, H, 2048);
+        SQ_LAUNCH_CHECK();
+    }
+#undef RUN
+    (void)act_cap;
+    return SQ_OK;
+}

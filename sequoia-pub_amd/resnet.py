@@ -1,0 +1,162 @@
+"""resnet50 -- host-side mirror of the interface /root/reference/pre_processing/compute_features_hdf5.py
+uses: ``model = resnet50(pretrained=True).to(device); model.eval(); model.forward_extract(x)``
+(src/resnet.py:370-379, :155-170), with torchvision's ``resnet50`` state_dict key names.
+
+The module keeps the reference's parameters/buffers (so ``load_state_dict`` of
+``resnet50-19c8e357.pth`` works unchanged); ``eval()``/first use folds BatchNorm into the
+convolutions in fp64 and packs the weights into the layout of ``sq_resnet50_layout``; all
+arithmetic then runs in ``sq_resnet50_extract``.  Training mode is not implemented (the reference
+only ever runs this network in eval mode, compute_features_hdf5.py:60)."""
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+LAYERS = (3, 4, 6, 3)
+PLANES = (64, 128, 256, 512)
+BN_EPS = 1e-5
+
+
+def conv_names():
+    """State-dict prefixes (conv, bn) in the kernel's conv order."""
+    names = [("conv1", "bn1")]
+    for li, nblocks in enumerate(LAYERS, start=1):
+        for b in range(nblocks):
+            p = f"layer{li}.{b}"
+            names += [(p + ".conv1", p + ".bn1"), (p + ".conv2", p + ".bn2"), (p + ".conv3", p + ".bn3")]
+            if b == 0:
+                names.append((p + ".downsample.0", p + ".downsample.1"))
+    return names
+
+
+def resnet50_layout():
+    lay = _lib.ResNet50Layout()
+    _lib.check(_lib.lib().sq_resnet50_layout_init(ctypes.byref(lay)))
+    return lay
+
+
+def pack_weights(sd, lay=None):
+    """state_dict -> (weights fp32 flat [w_total], bias fp32 flat [b_total]) with eval-mode BN folded (fp64)."""
+    lay = lay or resnet50_layout()
+    w = torch.zeros(lay.w_total, dtype=torch.float32)
+    b = torch.zeros(lay.b_total, dtype=torch.float32)
+    for i, (cn, bn) in enumerate(conv_names()):
+        d = lay.conv[i]
+        cw = sd[cn + ".weight"].detach().double().cpu()                  # [cout, cin, k, k]
+        assert tuple(cw.shape) == (d.cout, d.cin, d.k, d.k), (cn, tuple(cw.shape))
+        g = sd[bn + ".weight"].detach().double().cpu()
+        beta = sd[bn + ".bias"].detach().double().cpu()
+        mean = sd[bn + ".running_mean"].detach().double().cpu()
+        var = sd[bn + ".running_var"].detach().double().cpu()
+        scale = g / torch.sqrt(var + BN_EPS)
+        wf = (cw * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(d.cout, d.k * d.k * d.cin)   # [cout][kh][kw][cin]
+        if d.k_padded > wf.shape[1]:
+            wf = torch.cat([wf, torch.zeros(d.cout, d.k_padded - wf.shape[1], dtype=torch.float64)], 1)
+        w[d.w_off:d.w_off + d.cout * d.k_padded] = wf.reshape(-1).float()
+        b[d.b_off:d.b_off + d.cout] = (beta - mean * scale).float()
+    return w, b
+
+
+class ResNet50(nn.Module):
+    """Reference-shaped container (same parameter / buffer names as src/resnet.py ResNet(Bottleneck,[3,4,6,3]))."""
+
+    def __init__(self, num_classes=1000, compute_dtype="fp32"):
+        super().__init__()
+        self.compute_dtype = _lib.DTYPES[compute_dtype]
+
+        def conv(cout, cin, k):
+            c = nn.Conv2d(cin, cout, k, bias=False)
+            n = k * k * cout
+            c.weight.data.normal_(0, math.sqrt(2.0 / n))                  # resnet.py:113-116
+            return c
+
+        self.conv1 = conv(64, 3, 7)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for li, (nblocks, planes) in enumerate(zip(LAYERS, PLANES), start=1):
+            blocks = []
+            for b in range(nblocks):
+                blk = nn.Module()
+                blk.conv1, blk.bn1 = conv(planes, inplanes, 1), nn.BatchNorm2d(planes)
+                blk.conv2, blk.bn2 = conv(planes, planes, 3), nn.BatchNorm2d(planes)
+                blk.conv3, blk.bn3 = conv(planes * 4, planes, 1), nn.BatchNorm2d(planes * 4)
+                if b == 0:
+                    blk.downsample = nn.Sequential(conv(planes * 4, inplanes, 1), nn.BatchNorm2d(planes * 4))
+                blocks.append(blk)
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self.fc = nn.Linear(2048, num_classes)                            # unused by forward_extract, kept for checkpoints
+        self._packed = None
+        self._ws = None
+
+    # ---- packing -------------------------------------------------------------------------------
+    def _pack(self):
+        dev = self.conv1.weight.device
+        key = (dev, self.compute_dtype, tuple(p._version for p in self.parameters()))
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1], self._packed[2]
+        w, b = pack_weights(self.state_dict())
+        w = w.to(dev)
+        if self.compute_dtype == _lib.SQ_BF16:
+            w = w.to(torch.bfloat16)
+        self._packed = (key, w, b.to(dev))
+        return self._packed[1], self._packed[2]
+
+    def train(self, mode=True):
+        if mode and getattr(self, "_built", False):
+            raise NotImplementedError("sequoia-pub_amd ResNet50 runs in eval mode only (as the reference does)")
+        return super().train(mode)
+
+    def _run(self, patches_u8=None, x_f32=None):
+        _lib.require_gpu()
+        w, b = self._pack()
+        if not w.is_cuda:
+            raise _lib.SequoiaHipError("ResNet50 weights are on the CPU: call .to('cuda') first (no CPU fallback)")
+        src = patches_u8 if patches_u8 is not None else x_f32
+        n = src.shape[0]
+        S = src.shape[1] if patches_u8 is not None else src.shape[2]
+        feats = torch.empty(n, 2048, dtype=torch.float32, device=w.device)
+        need = _lib.lib().sq_resnet50_workspace_bytes(self.compute_dtype, n, S)
+        if need == 0:
+            raise ValueError(f"unsupported patch size {S} (need a multiple of 32, >= 224)")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != w.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.lib().sq_resnet50_extract(self.compute_dtype, _lib.ptr(w), _lib.ptr(b), _lib.ptr(patches_u8),
+                                                      _lib.ptr(x_f32), n, S, _lib.ptr(feats), _lib.ptr(self._ws),
+                                                      self._ws.numel(), _lib.stream_ptr(w.device)))
+        return feats
+
+    @torch.no_grad()
+    def forward_extract(self, x):
+        """src/resnet.py:155-170: x f32 [n, 3, H, W] (normalised) -> f32 [n, 2048]."""
+        dev = self.conv1.weight.device
+        return self._run(x_f32=x.to(dev, torch.float32).contiguous())
+
+    @torch.no_grad()
+    def extract_patches_u8(self, patches, sub_batch=64):
+        """uint8 HWC patches [n, S, S, 3] -> f32 [n, 2048]; fuses compute_features_hdf5.py:119-120's transform.
+        Patches are processed in sub-batches so the activations stay inside the 256 MiB Infinity Cache."""
+        dev = self.conv1.weight.device
+        patches = torch.as_tensor(patches)
+        outs = []
+        for i in range(0, patches.shape[0], sub_batch):
+            outs.append(self._run(patches_u8=patches[i:i + sub_batch].to(dev).contiguous()))
+        return torch.cat(outs, 0)
+
+    def forward(self, x):
+        raise NotImplementedError("only forward_extract is on the SEQUOIA path (fc is never used by the reference scripts)")
+
+
+def resnet50(pretrained=False, compute_dtype="fp32", **kwargs):
+    """src/resnet.py:370-379.  ``pretrained=True`` needs the torchvision checkpoint on disk or network."""
+    model = ResNet50(compute_dtype=compute_dtype, **kwargs)
+    if pretrained:
+        import torch.utils.model_zoo as model_zoo
+        model.load_state_dict(model_zoo.load_url("https://download.pytorch.org/models/resnet50-19c8e357.pth"))
+    model._built = True
+    return model

@@ -1,0 +1,53 @@
+"""HIP ResNet-50 forward_extract vs reference golden features (tests/golden/resnet50.npz) and the oracle.
+Tolerances: fp32 (exact-fp32 MFMA) 1e-4 relative; bf16 activations/weights 5e-2 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+from oracle import resnet_oracle as ro  # noqa: E402  (checker only)
+from sequoia_pub_amd import _lib, synth  # noqa: E402
+from sequoia_pub_amd.resnet import resnet50  # noqa: E402
+
+
+def _model(mode):
+    sd = ro.init_resnet50_state_dict(seed=99, perturb_bn=True)
+    m = resnet50(pretrained=False, compute_dtype=mode)
+    full = m.state_dict()
+    full.update(sd)
+    m.load_state_dict(full)
+    return m.to("cuda:0").eval(), sd
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+def test_features_match_reference_golden(golden_dir, mode, tol):
+    _lib.require_gpu()
+    z = np.load(os.path.join(golden_dir, "resnet50.npz"))
+    m, sd = _model(mode)
+    f224 = m.extract_patches_u8(synth.patches_u8(0, n_patches=2, size=224)).cpu().numpy()
+    f256 = m.extract_patches_u8(synth.patches_u8(1, n_patches=1, size=256)).cpu().numpy()
+    e224, e256 = rel_err(f224, z["feat224"]), rel_err(f256, z["feat256"])
+    print(f"resnet50 {mode}: rel err 224px {e224:.3e}  256px {e256:.3e}")
+    assert e224 < tol and e256 < tol
+
+
+def test_forward_extract_float_input_and_batch_consistency():
+    """reference call form (normalised fp32 NCHW, compute_features_hdf5.py:119-122) == fused uint8 path;
+    a batch of 5 == five single-patch calls (the reference loop is batch 1)."""
+    _lib.require_gpu()
+    m, sd = _model("fp32")
+    p = synth.patches_u8(3, n_patches=5, size=224)
+    fused = m.extract_patches_u8(p).cpu().numpy()
+    x = ro.transform_patch_u8(p)
+    direct = m.forward_extract(x).cpu().numpy()
+    assert rel_err(direct, fused) < 1e-6
+    singles = np.concatenate([m.extract_patches_u8(p[i:i + 1]).cpu().numpy() for i in range(5)])
+    assert np.array_equal(singles, fused)
+    with torch.no_grad():
+        ref = ro.forward_extract(sd, x).numpy()
+    assert rel_err(fused, ref) < 1e-4
