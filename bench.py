@@ -192,7 +192,55 @@ def workload_vis_train(args, rank, world, device):
                         "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient)" if world > 1 else "")})
 
 
-WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train}
+def workload_pipeline(args, rank, world, device):
+    """BASELINE config 3: 1000 x 224 x 224 uint8 patches/slide -> ResNet-50 -> k-Means(100) -> ViS forward."""
+    from sequoia_pub_amd.pipeline import SlidePipeline
+    from sequoia_pub_amd.resnet import resnet50
+    from sequoia_pub_amd.vis import ViS
+    nslides, npatch = args.slides, args.patches
+    torch.manual_seed(99)
+    rn = resnet50(pretrained=False, compute_dtype=args.dtype).to(device).eval()
+    for m in rn.modules():                     # non-trivial BN statistics so folding is exercised
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    cfg = dict(VIS_CFG, input_dim=2048)
+    vis = ViS(**cfg, num_clusters=100, device=str(device), compute_dtype=args.dtype).to(device).eval()
+    pipe = SlidePipeline(rn, vis, sub_batch=args.sub_batch)
+    slides = [torch.from_numpy(synth.patches_u8(rank * nslides + i, npatch, 224)).to(device) for i in range(nslides)]
+
+    def step():
+        pipe(slides)
+
+    def cpu_baseline():
+        from oracle import kmeans_oracle, resnet_oracle, vis_oracle
+        sd_r = {k: v.cpu() for k, v in rn.state_dict().items()}
+        sd_v = {k: v.cpu() for k, v in vis.state_dict().items()}
+        patches = slides[0][:32].cpu()
+
+        def embed():
+            resnet_oracle.embed_patches(sd_r, patches, batch=32)
+        rate, threads, reps = timed_cpu_sample(embed, 32, budget_s=10.0)
+        feats = synth.features_gmm(5, npatch, 2048)
+        t0 = time.perf_counter()
+        r = kmeans_oracle.kmeans_fit(feats)
+        cf = kmeans_oracle.cluster_means(feats, r["labels"])
+        with torch.no_grad():
+            vis_oracle.vis_forward(sd_v, torch.from_numpy(cf)[None])
+        t_rest = time.perf_counter() - t0
+        per_slide = npatch / rate + t_rest
+        return {"value": round(1.0 / per_slide, 5), "unit": "slides/s", "cores": threads, "kind": "port",
+                "sample": f"oracle ResNet-50 on {reps} x 32 patches (batched; {rate:.1f} patches/s) extrapolated to "
+                          f"{npatch} patches + one oracle k-Means + ViS forward ({t_rest:.2f} s)"}
+
+    return dict(step=step, slides_per_step=nslides, cpu_baseline=cpu_baseline,
+                config={"workload": "pipeline: 1000 x 224x224 uint8 patches/slide -> ResNet-50 embed -> k-Means(100) -> "
+                                    "ViS(D=2048, depth 6, 16 heads, G=20820) forward (BASELINE config 3), patches resident in HBM",
+                        "slides_per_step_per_gpu": nslides, "patches_per_slide": npatch,
+                        "parallelism": f"slide-sharded x{world}"})
+
+
+WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train, "pipeline": workload_pipeline}
 
 
 def main():
@@ -203,6 +251,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "vis_train"), choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=64, help="slides per GPU per step")
+    ap.add_argument("--slides", type=int, default=2, help="pipeline workload: slides per GPU per step")
+    ap.add_argument("--patches", type=int, default=1000, help="pipeline workload: patches per slide")
+    ap.add_argument("--sub-batch", type=int, default=100, help="pipeline workload: patches per ResNet launch group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -167,12 +167,12 @@ int sq_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, sq_stream_t 
  * Fused linear layer  C = act(A . W^T + bias + residual)   -- the nn.Linear call sites of
  * src/tformer_lin.py:14-16,37,55,57,93 and the 1x1 convolutions of src/resnet.py:60,66.
  * A [M,K] (lda) and W [N,K] (ldw) are `dtype` (f32 or bf16), bias f32 [N] or NULL,
- * residual f32 [M,N] (ldres) or NULL, act: 0 none, 1 exact-erf GELU, 2 ReLU,
+ * residual [M,N] (ldres; res_dtype f32 or bf16) or NULL, act: 0 none, 1 exact-erf GELU, 2 ReLU,
  * C [M,N] (ldc) in out_dtype.  K, lda, ldw multiples of 16 bytes / element size.
  * workspace (optional fp32 scratch, may be NULL): lets skinny problems run split-K.
  * ---------------------------------------------------------------------------- */
-int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual,
-              int ldres, int act, void* C, int out_dtype, int ldc, int M, int N, int K, void* workspace,
+int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
+              int ldres, int res_dtype, int act, void* C, int out_dtype, int ldc, int M, int N, int K, void* workspace,
               size_t workspace_bytes, sq_stream_t stream);
 
 #ifdef __cplusplus

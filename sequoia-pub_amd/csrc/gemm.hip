@@ -54,8 +54,10 @@ template <> struct Mma<bf16_t> {
     }
 };
 
-// Epilogue of one 4-wide chunk (row m, columns n..n+cnt-1); v holds the raw accumulators.
-__device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m, int n, float (&v)[4], int cnt, bool vec) {
+// Epilogue of one 8-wide chunk (row m, columns n..n+cnt-1); v holds the raw accumulators.
+// Vector path: 2 x 16-byte fp32 accesses / one 16-byte bf16 access per operand.
+__device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m, int n, float (&v)[8], int cnt, bool vec,
+                                          const float* pre_res = nullptr, const float* pre_bias = nullptr) {
     const float* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
     const float* rowbias = p.rowbias ? p.rowbias + (long long)z * p.sRb : nullptr;
     const float* res32 = (p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
@@ -66,27 +68,55 @@ __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m, int n
     float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
     const float* gg = p.gelu_grad_of ? p.gelu_grad_of + (long long)z * p.sGg : nullptr;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
     const long long rb_row = rowbias ? (long long)(m / p.rows_per_group) * p.ldrb : 0;
-    if (vec && cnt == 4) {
-        if (bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(bias + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-        if (rowbias) { const f32x4 t = *reinterpret_cast<const f32x4*>(rowbias + rb_row + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-        if (res32) { const f32x4 t = *reinterpret_cast<const f32x4*>(res32 + (long long)m * p.ldres + n); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
-        if (res16) {
-            const u32x2 t = *reinterpret_cast<const u32x2*>(res16 + (long long)m * p.ldres + n);
-            v[0] += __uint_as_float(t[0] << 16); v[1] += __uint_as_float(t[0] & 0xffff0000u);
-            v[2] += __uint_as_float(t[1] << 16); v[3] += __uint_as_float(t[1] & 0xffff0000u);
+    auto add8 = [&](const float* src) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+        v[0] += t0[0]; v[1] += t0[1]; v[2] += t0[2]; v[3] += t0[3]; v[4] += t1[0]; v[5] += t1[1]; v[6] += t1[2]; v[7] += t1[3];
+    };
+    auto st8 = [&](float* dst) {
+        const f32x4 t0 = {v[0], v[1], v[2], v[3]}, t1 = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(dst) = t0; *reinterpret_cast<f32x4*>(dst + 4) = t1;
+    };
+    auto st8h = [&](bf16_t* dst) {
+        const u32x4 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(dst) = t;
+    };
+    if (vec && cnt == 8) {
+        if (pre_bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += pre_bias[e];
+        } else if (bias) {
+            add8(bias + n);
         }
-        if (cpre) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(cpre + (long long)m * p.ldpre + n) = t; }
-        if (p.act == SQ_ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-        else if (p.act == SQ_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (rowbias) add8(rowbias + rb_row + n);
+        if (pre_res) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += pre_res[e];
+        } else if (res32) {
+            add8(res32 + (long long)m * p.ldres + n);
+        } else if (res16) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(res16 + (long long)m * p.ldres + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(t[e] << 16); v[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
+        }
+        if (cpre) st8(cpre + (long long)m * p.ldpre + n);
+        if (p.act == SQ_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        } else if (p.act == SQ_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         if (gg) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(gg + (long long)m * p.ldgg + n);
-            v[0] *= gelu_erf_grad(t[0]); v[1] *= gelu_erf_grad(t[1]); v[2] *= gelu_erf_grad(t[2]); v[3] *= gelu_erf_grad(t[3]);
+            const float* gs = gg + (long long)m * p.ldgg + n;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(gs), t1 = *reinterpret_cast<const f32x4*>(gs + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] *= gelu_erf_grad(t0[e]); v[4 + e] *= gelu_erf_grad(t1[e]); }
         }
-        if (c32) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(c32 + (long long)m * p.ldc + n) = t; }
-        if (c16p) { u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(c16p + (long long)m * p.ldc + n) = t; }
-        if (c2) { u32x2 t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(c2 + (long long)m * p.ldc2 + n) = t; }
+        if (c32) st8(c32 + (long long)m * p.ldc + n);
+        if (c16p) st8h(c16p + (long long)m * p.ldc + n);
+        if (c2) st8h(c2 + (long long)m * p.ldc2 + n);
     } else {
         for (int e = 0; e < cnt; ++e) {
             float x = v[e];
@@ -172,6 +202,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     for (int j = 0; j < RB; ++j) {
         const int n = n0 + r0 + 32 * j;
         b_off[j] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(gc * EPC)) * (uint32_t)sizeof(T) : OOB;
+    }
+
+    // Epilogue operands that do not depend on the accumulators are requested NOW, so their HBM latency
+    // hides under the K loop: each thread owns one fixed 8-column chunk and ITER rows of the tile.
+    constexpr int BN8 = BN / 8;
+    constexpr int RPI = 256 / BN8;          // rows covered per epilogue iteration
+    constexpr int ITER = BM / RPI;
+    const int e_c8 = tid % BN8, e_rbase = tid / BN8;
+    const int e_n = n0 + e_c8 * 8;
+    const int e_cnt = min(8, p.N - e_n);
+    const bool e_vec = p.vec_epi != 0 && e_cnt == 8 && p.splitk == 1;
+    const bool pre16 = e_vec && p.res != nullptr && p.res_dtype == SQ_BF16;
+    u32x4 rr16[ITER];
+    float bias8[8];
+    if (pre16) {
+        const bf16_t* r16 = reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes;
+#pragma unroll
+        for (int u = 0; u < ITER; ++u) {
+            const int m = m0 + e_rbase + u * RPI;
+            rr16[u] = m < p.M ? *reinterpret_cast<const u32x4*>(r16 + (long long)m * p.ldres + e_n) : u32x4{0, 0, 0, 0};
+        }
+    }
+    const bool pre_b = e_vec && p.bias != nullptr;
+    if (pre_b) {
+        const float* bsrc = p.bias + (long long)z * p.sBias + e_n;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(bsrc), t1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = t0[e]; bias8[4 + e] = t1[e]; }
     }
 
     // tile kt -> LDS buffer buf, asynchronously (completion: vmcnt, drained by the barrier's fence)
@@ -290,34 +348,49 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         }
         return;
     }
+    if (e_cnt <= 0) return;
+    // vmcnt counts stores as well as loads, so a global load issued after a store waits for that store's
+    // write acknowledgement: bias / bf16 residual were fetched before the K loop; the other optional
+    // operands (fp32 residual, row bias, GELU' source) are still read inside epi_apply.
     const bool vec = p.vec_epi != 0;
-#pragma unroll 1
-    for (int idx = tid; idx < BM * BN4; idx += 256) {
-        const int row = idx / BN4, c4 = idx - row * BN4;
-        const int m = m0 + row, n = n0 + c4 * 4;
-        if (m >= p.M || n >= p.N) continue;
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(stage + row * BN + c4 * 4);
-        float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-        epi_apply(p, z, m, n, v, min(4, p.N - n), vec);
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {
+        const int row = e_rbase + u * RPI;
+        const int m = m0 + row;
+        if (m < p.M) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8 + 4);
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            float rv[8];
+            if (pre16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rv[2 * e] = __uint_as_float(rr16[u][e] << 16); rv[2 * e + 1] = __uint_as_float(rr16[u][e] & 0xffff0000u); }
+            }
+            epi_apply(p, z, m, e_n, v, e_cnt, vec, pre16 ? rv : nullptr, pre_b ? bias8 : nullptr);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep iterations from being interleaved (register pressure)
     }
 }
 
-// sums the K-slice partials in slice order, then the normal epilogue
+// sums the K-slice partials in slice order, then the normal epilogue (N % 8 == 0 enforced by the launcher)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
-    const int N4 = p.N / 4;
-    const size_t total = (size_t)p.M * N4;
+    const int N8 = p.N / 8;
+    const size_t total = (size_t)p.M * N8;
     const int z = blockIdx.z;
     const float* base = p.splitk_ws + (size_t)z * p.splitk * (size_t)p.M * p.N;
     const bool vec = p.vec_epi != 0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(idx / N4), n = (int)(idx - (size_t)m * N4) * 4;
-        f32x4 s = *reinterpret_cast<const f32x4*>(base + (size_t)m * p.N + n);
+        const int m = (int)(idx / N8), n = (int)(idx - (size_t)m * N8) * 8;
+        const float* src = base + (size_t)m * p.N + n;
+        f32x4 s0 = *reinterpret_cast<const f32x4*>(src), s1 = *reinterpret_cast<const f32x4*>(src + 4);
         for (int k = 1; k < p.splitk; ++k) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(base + (size_t)k * p.M * p.N + (size_t)m * p.N + n);
-            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+            const float* sk = src + (size_t)k * p.M * p.N;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(sk), t1 = *reinterpret_cast<const f32x4*>(sk + 4);
+            s0[0] += t0[0]; s0[1] += t0[1]; s0[2] += t0[2]; s0[3] += t0[3];
+            s1[0] += t1[0]; s1[1] += t1[1]; s1[2] += t1[2]; s1[3] += t1[3];
         }
-        float v[4] = {s[0], s[1], s[2], s[3]};
-        epi_apply(p, z, m, n, v, 4, vec);
+        float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        epi_apply(p, z, m, n, v, 8, vec);
     }
 }
 
@@ -331,7 +404,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     else hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, false>), grid, block, lds, stream, a);
     SQ_LAUNCH_CHECK();
     if (a.splitk > 1) {
-        size_t nb = ((size_t)a.M * (a.N / 4) + 255) / 256;
+        size_t nb = ((size_t)a.M * (a.N / 8) + 255) / 256;
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb, 1, a.batch), dim3(256), 0, stream, a);
         SQ_LAUNCH_CHECK();
@@ -361,14 +434,14 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
     a.splitk = 1;
     const int nk = (a.K + 8 * epc - 1) / (8 * epc);
     const long long nb = blocks(bm, bn);
-    if (a.splitk_ws && a.N % 4 == 0 && nb < 256 && nk >= 4) {
+    if (a.splitk_ws && a.N % 8 == 0 && nb < 256 && nk >= 4) {
         long long s = (512 + nb - 1) / nb;
         if (s > nk / 2) s = nk / 2;
         if (s > 32) s = 32;
         while (s > 1 && (size_t)s * a.M * a.N * a.batch * sizeof(float) > a.splitk_ws_bytes) --s;
         if (s > 1) a.splitk = (int)s;
     }
-    if (g_force_split > 0 && a.splitk_ws) a.splitk = g_force_split;
+    if (g_force_split > 0 && a.splitk_ws && a.N % 8 == 0) a.splitk = g_force_split;
     if (tile == 22) return launch_cfg<T, 2, 2>(a, stream);
     if (tile == 21) return launch_cfg<T, 2, 1>(a, stream);
     if (tile == 12) return launch_cfg<T, 1, 2>(a, stream);
@@ -406,10 +479,7 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
         auto al = [](const void* ptr, int ld, long long st, int elem) {
             return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
         };
-        // bf16 rows are written 8 bytes at a time: 8-byte alignment is enough for them
-        auto al8 = [](const void* ptr, int ld, long long st) {
-            return ptr == nullptr || (((uintptr_t)ptr % 8) == 0 && (ld * 2) % 8 == 0 && ((st * 2) % 8) == 0);
-        };
+        auto al8 = [&](const void* ptr, int ld, long long st) { return al(ptr, ld, st, 2); };   // bf16 rows: 16-byte accesses
         bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, 4) &&
                   al(a.gelu_grad_of, a.ldgg, a.sGg, 4) && al8(a.C2, a.ldc2, a.sC2);
         ok = ok && (a.out_dtype == SQ_F32 ? al(a.C, a.ldc, a.sC, 4) : al8(a.C, a.ldc, a.sC));

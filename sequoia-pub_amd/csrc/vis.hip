@@ -222,8 +222,8 @@ extern "C" int sq_cast_f32_to_bf16(const float* src, void* dst, size_t n, sq_str
     return sq_k_f32_to_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream);
 }
 
-extern "C" int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual,
-                         int ldres, int act, void* C, int out_dtype, int ldc, int M, int N, int K, void* workspace,
+extern "C" int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
+                         int ldres, int res_dtype, int act, void* C, int out_dtype, int ldc, int M, int N, int K, void* workspace,
                          size_t workspace_bytes, sq_stream_t stream) {
     SQ_REQUIRE(A && W && C, "linear: null pointer");
     SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16, "linear: dtype %d", dtype);
@@ -231,7 +231,7 @@ extern "C" int sq_linear(int dtype, const void* A, int lda, const void* W, int l
     const size_t es = sq_dtype_size(dtype);
     g.A = A; g.lda = lda; g.a_bytes = ((size_t)(M - 1) * lda + K) * es;
     g.B = W; g.ldb = ldw; g.b_bytes = ((size_t)(N - 1) * ldw + K) * es;
-    g.bias = bias; g.res = residual; g.ldres = ldres; g.act = act;
+    g.bias = bias; g.res = residual; g.ldres = ldres; g.res_dtype = res_dtype; g.act = act;
     g.C = C; g.out_dtype = out_dtype; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.splitk_ws = (float*)workspace; g.splitk_ws_bytes = workspace_bytes;
     return sq_launch_gemm(g, dtype, (hipStream_t)stream);

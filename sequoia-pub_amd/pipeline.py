@@ -1,0 +1,47 @@
+"""End-to-end slide pipeline on one GPU: uint8 patches -> ResNet-50 features -> per-slide k-Means(100)
+-> cluster means -> ViS -> gene-expression vector.
+
+This is the composition the reference performs through files:
+  pre_processing/compute_features_hdf5.py:116-136  ->  "<feat_type>_features" [n, 2048]
+  pre_processing/kmean_features.py:96-108          ->  "cluster_features"     [100, 2048]
+  evaluation/predict_independent_dataset.py:54-91  ->  predictions [n_slides, G]
+kept on the device between stages (BASELINE config 3)."""
+import torch
+
+from . import _lib
+from .kmeans import kmeans_fit_batch
+
+
+class SlidePipeline:
+    def __init__(self, resnet, vis, n_clusters=100, sub_batch=100):
+        self.resnet = resnet
+        self.vis = vis
+        self.n_clusters = n_clusters
+        self.sub_batch = sub_batch
+
+    @torch.no_grad()
+    def embed(self, patches_u8):
+        """[n, S, S, 3] uint8 (device or host) -> f32 [n, 2048] on the device."""
+        return self.resnet.extract_patches_u8(patches_u8, sub_batch=self.sub_batch)
+
+    @torch.no_grad()
+    def cluster(self, features):
+        """[S, n, D] f32 -> (cluster_features [S, 100, D], labels [S, n])."""
+        r = kmeans_fit_batch(features, self.n_clusters, random_state=0)
+        return r["cluster_features"], r["labels"]
+
+    @torch.no_grad()
+    def __call__(self, slides_u8):
+        """slides_u8: list of [n_i, S, S, 3] uint8 tensors, or one [S, n, S, S, 3] tensor.
+        Returns dict(pred [S, G], cluster_features [S, 100, D], labels list)."""
+        feats = [self.embed(p) for p in slides_u8]
+        same = all(f.shape[0] == feats[0].shape[0] for f in feats)
+        if same:
+            cf, labels = self.cluster(torch.stack(feats))
+            labels = list(labels)
+        else:                                   # ragged patch counts: one k-Means call per slide
+            outs = [self.cluster(f.unsqueeze(0)) for f in feats]
+            cf = torch.cat([o[0] for o in outs])
+            labels = [o[1][0] for o in outs]
+        pred = self.vis(cf)
+        return dict(pred=pred, cluster_features=cf, labels=labels, features=feats)

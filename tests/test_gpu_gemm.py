@@ -26,7 +26,7 @@ def run_linear(dtype, A, W, bias, res, act, out_bf16=False, ws_bytes=0):
     rd = res.to(dev) if res is not None else None
     C = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-    _lib.check(_lib.lib().sq_linear(dtype, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(bd), _lib.ptr(rd), N, act,
+    _lib.check(_lib.lib().sq_linear(dtype, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(bd), _lib.ptr(rd), N, _lib.SQ_F32, act,
                                     _lib.ptr(C), _lib.SQ_BF16 if out_bf16 else _lib.SQ_F32, N, M, N, K,
                                     _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
     torch.cuda.synchronize()
@@ -95,6 +95,6 @@ def test_split_k_path(M, N, K, dtype):
 def test_bad_arguments_fail_loudly():
     _lib.require_gpu()
     A = torch.zeros(4, 6, device="cuda")
-    rc = _lib.lib().sq_linear(_lib.SQ_F32, _lib.ptr(A), 6, _lib.ptr(A), 6, None, None, 0, 0, _lib.ptr(A), 0, 4, 4, 4, 6,
+    rc = _lib.lib().sq_linear(_lib.SQ_F32, _lib.ptr(A), 6, _lib.ptr(A), 6, None, None, 0, 0, 0, _lib.ptr(A), 0, 4, 4, 4, 6,
                               None, 0, _lib.stream_ptr())
     assert rc != 0 and b"multiple" in _lib.lib().sq_last_error()
