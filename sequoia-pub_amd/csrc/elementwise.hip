@@ -15,22 +15,34 @@ __global__ void add_pos_kernel(const float4* __restrict__ x, const float4* __res
     }
 }
 
-// thread = (b, d4): adds the N token rows in index order (deterministic fp32 order)
-__global__ void token_mean_kernel(const float4* __restrict__ X, float4* __restrict__ out, uint2* __restrict__ outh,
-                                  int B, int N, int D4) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * D4) return;
-    const int b = i / D4, d = i - b * D4;
-    const float4* p = X + (size_t)b * N * D4 + d;
+// thread = (b, d4, quarter of the tokens); quarters combined through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void token_mean_kernel(const float4* __restrict__ X, float4* __restrict__ out, uint2* __restrict__ outh,
+                                                         int B, int N, int D4) {
+    __shared__ float4 red[4][64];
+    const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = 0; n < N; ++n) {
-        const float4 v = p[(size_t)n * D4];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    if (i < B * D4) {
+        const int b = i / D4, d = i - b * D4;
+        const float4* p = X + (size_t)b * N * D4 + d;
+        const int per = (N + 3) / 4, lo = q * per, hi = min(N, lo + per);
+        for (int n = lo; n < hi; ++n) {
+            const float4 v = p[(size_t)n * D4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
-    const float inv = 1.0f / (float)N;
-    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
-    out[i] = acc;
-    if (outh) outh[i] = make_uint2(pack_bf16x2(acc.x, acc.y), pack_bf16x2(acc.z, acc.w));
+    red[q][tx] = acc;
+    __syncthreads();
+    if (q == 0 && i < B * D4) {
+        const float inv = 1.0f / (float)N;
+        float4 r;
+        r.x = ((red[0][tx].x + red[1][tx].x) + (red[2][tx].x + red[3][tx].x)) * inv;
+        r.y = ((red[0][tx].y + red[1][tx].y) + (red[2][tx].y + red[3][tx].y)) * inv;
+        r.z = ((red[0][tx].z + red[1][tx].z) + (red[2][tx].z + red[3][tx].z)) * inv;
+        r.w = ((red[0][tx].w + red[1][tx].w) + (red[2][tx].w + red[3][tx].w)) * inv;
+        out[i] = r;
+        if (outh) outh[i] = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
+    }
 }
 
 // one wave per row; row kept in registers between the mean and variance passes
@@ -183,7 +195,7 @@ int sq_k_add_pos(const float* x, const float* pos, float* X, bf16_t* Xh, int B, 
 int sq_k_token_mean(const float* X, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s) {
     SQ_REQUIRE(D % 4 == 0, "token_mean: D=%d must be a multiple of 4", D);
     const int total = B * (D / 4);
-    hipLaunchKernelGGL(token_mean_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float4*)X, (float4*)out,
+    hipLaunchKernelGGL(token_mean_kernel, dim3((total + 63) / 64), dim3(256), 0, s, (const float4*)X, (float4*)out,
                        (uint2*)outh, B, N, D / 4);
     SQ_LAUNCH_CHECK();
     return SQ_OK;

@@ -29,12 +29,54 @@ __global__ __launch_bounds__(256) void colsum_stage1(const T* __restrict__ x, in
     if (ty == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
-__global__ void colsum_stage2(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// stage 2: block = 64 columns x 4 groups of partials (fixed order -> deterministic); columns >= split go to out2
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ out,
+                                                     float* __restrict__ out2, int split) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float acc = 0.f;
-    for (int s = 0; s < nsplit; ++s) acc += partial[(size_t)s * C + c];
-    out[c] = acc;
+    if (c < C)
+        for (int s = ty; s < nsplit; s += 4) acc += partial[(size_t)s * C + c];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (out2 && c >= split) out2[c - split] = v;
+        else out[c] = v;
+    }
+}
+
+// out[g, c] = scale * sum_n x[g*N + n, c]: thread = (g, 4-column chunk, quarter of the rows); the four
+// quarters are combined through LDS in a fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void group_sum4_kernel(const T* __restrict__ x, int G, int N, int C4, float scale,
+                                                         float* __restrict__ out, T* __restrict__ out_lp) {
+    __shared__ float4 red[4][64];
+    const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;            // (g, c4) flat
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < G * C4) {
+        const int g = i / C4, c4 = i - g * C4;
+        const int per = (N + 3) / 4, lo = q * per, hi = min(N, lo + per);
+        for (int n = lo; n < hi; ++n) {
+            const size_t e = (((size_t)g * N + n) * C4 + c4) * 4;
+            acc.x += ld_as_f32<T>(x, e); acc.y += ld_as_f32<T>(x, e + 1); acc.z += ld_as_f32<T>(x, e + 2); acc.w += ld_as_f32<T>(x, e + 3);
+        }
+    }
+    red[q][tx] = acc;
+    __syncthreads();
+    if (q == 0 && i < G * C4) {
+        float4 r;
+        r.x = ((red[0][tx].x + red[1][tx].x) + (red[2][tx].x + red[3][tx].x)) * scale;
+        r.y = ((red[0][tx].y + red[1][tx].y) + (red[2][tx].y + red[3][tx].y)) * scale;
+        r.z = ((red[0][tx].z + red[1][tx].z) + (red[2][tx].z + red[3][tx].z)) * scale;
+        r.w = ((red[0][tx].w + red[1][tx].w) + (red[2][tx].w + red[3][tx].w)) * scale;
+        reinterpret_cast<float4*>(out)[i] = r;
+        if (out_lp) {
+            if constexpr (sizeof(T) == 2) reinterpret_cast<uint2*>(out_lp)[i] = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
+        }
+    }
 }
 
 template <typename T>
@@ -206,7 +248,8 @@ __global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const float* __restr
     }
 }
 
-int colsum_impl(const void* x, int dtype, int R, int C, int ld, float* ws, float* out, hipStream_t s) {
+int colsum_impl(const void* x, int dtype, int R, int C, int ld, float* ws, float* out, hipStream_t s, float* out2 = nullptr,
+                int split = 0) {
     int nsplit = (R + 63) / 64;
     if (nsplit > COLSUM_SPLITS) nsplit = COLSUM_SPLITS;
     if (nsplit < 1) nsplit = 1;
@@ -215,7 +258,7 @@ int colsum_impl(const void* x, int dtype, int R, int C, int ld, float* ws, float
     if (dtype == SQ_BF16) hipLaunchKernelGGL(colsum_stage1<bf16_t>, grid, block, 0, s, (const bf16_t*)x, R, C, ld, rows_per_split, ws);
     else hipLaunchKernelGGL(colsum_stage1<float>, grid, block, 0, s, (const float*)x, R, C, ld, rows_per_split, ws);
     SQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, ws, nsplit, C, out);
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, s, ws, nsplit, C, out, out2, split);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
@@ -230,6 +273,13 @@ int sq_k_colsum(const void* x, int dtype, int R, int C, int ld, float* ws, float
 }
 
 int sq_k_group_sum(const void* x, int dtype, int G, int N, int C, float scale, float* out, hipStream_t s) {
+    if (C % 4 == 0) {
+        const int items = G * (C / 4);
+        if (dtype == SQ_BF16) hipLaunchKernelGGL(group_sum4_kernel<bf16_t>, dim3((items + 63) / 64), dim3(256), 0, s, (const bf16_t*)x, G, N, C / 4, scale, out, (bf16_t*)nullptr);
+        else hipLaunchKernelGGL(group_sum4_kernel<float>, dim3((items + 63) / 64), dim3(256), 0, s, (const float*)x, G, N, C / 4, scale, out, (float*)nullptr);
+        SQ_LAUNCH_CHECK();
+        return SQ_OK;
+    }
     const int total = G * C;
     if (dtype == SQ_BF16) hipLaunchKernelGGL(group_sum_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16_t*)x, G, N, C, scale, out);
     else hipLaunchKernelGGL(group_sum_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)x, G, N, C, scale, out);
@@ -267,11 +317,7 @@ int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const floa
     SQ_LAUNCH_CHECK();
     // partial rows are [dg | db] of length 2D: one column-sum over nblk*4 partial rows, then split
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * D;
-    float* both = cs_ws + sq_colsum_ws_floats(2 * D) - 2 * D;     // tail of the colsum scratch is free: nsplit <= 16 here
-    if (int e = colsum_impl(ws, SQ_F32, nblk * 4, 2 * D, 2 * D, cs_ws, both, s)) return e;
-    SQ_HIP_CHECK(hipMemcpyAsync(dg, both, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
-    SQ_HIP_CHECK(hipMemcpyAsync(db, both + D, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
-    return SQ_OK;
+    return colsum_impl(ws, SQ_F32, nblk * 4, 2 * D, 2 * D, cs_ws, dg, s, db, D);
 }
 
 int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const float* b, void* dx, int out_dtype, float* dg,
@@ -290,9 +336,5 @@ int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const fl
     else hipLaunchKernelGGL(ln64_gelu_bwd_kernel<4>, grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
     SQ_LAUNCH_CHECK();
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * C;
-    float* both = cs_ws + sq_colsum_ws_floats(2 * C) - 2 * C;
-    if (int e = colsum_impl(ws, SQ_F32, nblk * rpi, 2 * C, 2 * C, cs_ws, both, s)) return e;
-    SQ_HIP_CHECK(hipMemcpyAsync(dg, both, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
-    SQ_HIP_CHECK(hipMemcpyAsync(db, both + C, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
-    return SQ_OK;
+    return colsum_impl(ws, SQ_F32, nblk * rpi, 2 * C, 2 * C, cs_ws, dg, s, db, C);
 }

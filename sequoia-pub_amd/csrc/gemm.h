@@ -40,5 +40,11 @@ struct GemmArgs {
 
 // dtype: SQ_F32 (v_mfma_f32_32x32x2_f32, exact fp32) or SQ_BF16 (v_mfma_f32_32x32x16_bf16)
 int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream);
+// TN product for weight gradients:  C[M,N] = alpha * sum_k A[k, M-index] * B[k, N-index]
+//   A [K, M] (lda) and B [K, N] (ldb) are row-major with the CONTRACTION index as the row, i.e. the
+//   activations exactly as the forward pass stored them (no transposed copies).  a.M / a.N = extents of C,
+//   a.K = number of rows contracted.  Same epilogue / split-K fields as sq_launch_gemm.
+int sq_launch_gemm_tn(const GemmArgs& a, int dtype, hipStream_t stream);
+int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream);
 // experiment knobs (not part of the product ABI): key 0 = forced tile (WTM*10+WTN, 0 = auto), key 1 = dbg flags
 extern "C" int sq_dbg_set(int key, int value);

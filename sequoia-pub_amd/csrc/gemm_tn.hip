@@ -1,0 +1,232 @@
+// TN GEMM for weight gradients on gfx950:   C[M,N] = alpha * sum_k A[k,m] * B[k,n]
+//
+// dW = dY^T . X contracts over TOKENS, and both operands are stored token-major (row = token) by the
+// forward pass.  Instead of materialising transposed copies, the token-major tiles are DMA'd into LDS
+// as they are (rows of 128 outputs = 256 B bf16 / 512 B fp32, fully coalesced) and the MFMA fragments are
+// read "down the columns":
+//   bf16: v_mfma_f32_16x16x32_bf16 -- lane (i = l&15, g = l>>4) needs k = 8g..8g+7 of column i:
+//         eight ds_read_u16 per fragment, 16-B chunks XOR-swizzled by 2*((row>>3)&3) on the DMA source
+//         so the four lane groups of one read hit disjoint banks
+//   fp32: v_mfma_f32_16x16x4_f32   -- lane (i, g) needs row g of column i: one conflict-free ds_read_b32
+//         (chunks swizzled by (row&3)<<2)
+// Block = 128 x 128 outputs, 4 waves (2x2) x 4x4 MFMA tiles, contraction walked 64 (bf16) / 32 (fp32) rows
+// per step with two LDS buffers; grid.y slices the contraction (split-K, deterministic reduction).
+#include "gemm.h"
+#include "gemm_epi.h"
+
+#include <cstdio>
+
+namespace {
+
+constexpr uint32_t OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, uint32_t voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_base, 16, voffset, soffset, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
+    constexpr bool LP = sizeof(T) == 2;
+    constexpr int BT = 128;                        // outputs per tile side
+    constexpr int ROWB = BT * (int)sizeof(T);      // bytes per LDS row (256 / 512)
+    constexpr int KR = LP ? 64 : 32;               // contraction rows per step
+    constexpr int TILE_BYTES = KR * ROWB;          // 16 KiB per operand
+    constexpr int CHUNKS = ROWB / 16;              // 16-B chunks per row (16 / 32)
+    constexpr int ROWS_PER_INSTR = 1024 / ROWB;    // rows one wave DMA instruction fills (4 / 2)
+    constexpr int NINSTR = KR / (4 * ROWS_PER_INSTR);   // DMA instructions per thread per operand (4 / 4)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BT - 1) / BT;
+    const int m0 = (blockIdx.x / tiles_n) * BT, n0 = (blockIdx.x % tiles_n) * BT;
+    const int z = blockIdx.z;
+
+    const T* Ab = reinterpret_cast<const T*>(p.A) + (long long)z * p.sA;
+    const T* Bb = reinterpret_cast<const T*>(p.B) + (long long)z * p.sB;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(p.a_bytes - (size_t)z * p.sA * sizeof(T)), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(p.b_bytes - (size_t)z * p.sB * sizeof(T)), 0x00020000);
+
+    // DMA lane mapping: instruction j of wave w fills rows (j*4 + w) * ROWS_PER_INSTR + lane / CHUNKS
+    const int lrow = lane / CHUNKS, lchunk = lane % CHUNKS;
+    auto key = [](int row) { return LP ? (((row >> 3) & 3) << 1) : ((row & 3) << 2); };
+
+    const int nk_all = (p.K + KR - 1) / KR;
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    const int kt_lo = blockIdx.y * per, kt_hi = min(nk_all, kt_lo + per);
+
+    auto issue = [&](int kt, int buf) {
+        char* sa = smem + buf * (2 * TILE_BYTES);
+        char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NINSTR; ++j) {
+            const int rbase = (j * 4 + wave) * ROWS_PER_INSTR;
+            const int row = rbase + lrow;                       // row inside the step
+            const int k = kt * KR + row;                        // contraction index
+            const int gchunk = lchunk ^ key(row);               // source chunk landing at LDS chunk lchunk
+            const int ca = m0 + gchunk * (16 / (int)sizeof(T)), cb = n0 + gchunk * (16 / (int)sizeof(T));
+            const uint32_t oa = (k < p.K && ca < p.M) ? (uint32_t)(((long long)k * p.lda + ca) * (long long)sizeof(T)) : OOB;
+            const uint32_t ob = (k < p.K && cb < p.N) ? (uint32_t)(((long long)k * p.ldb + cb) * (long long)sizeof(T)) : OOB;
+            glds16(rsA, sa + rbase * ROWB, oa, 0);
+            glds16(rsB, sb + rbase * ROWB, ob, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int li = lane & 15, lg = lane >> 4;
+
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * (2 * TILE_BYTES);
+        const char* sb = sa + TILE_BYTES;
+        if constexpr (LP) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                       // two k-steps of 32 rows
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ca = wm * 64 + t * 16 + li, cb = wn * 64 + t * 16 + li;     // column inside the tile
+                    union { bf16x8 h; uint16_t u[8]; } ua, ub;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = 32 * s + 8 * lg + j;
+                        const int kx = ((row >> 3) & 3) << 1;   // = 2 * lg
+                        ua.u[j] = *reinterpret_cast<const uint16_t*>(sa + row * ROWB + (((ca >> 3) ^ kx) << 4) + ((ca & 7) << 1));
+                        ub.u[j] = *reinterpret_cast<const uint16_t*>(sb + row * ROWB + (((cb >> 3) ^ kx) << 4) + ((cb & 7) << 1));
+                    }
+                    fa[t] = ua.h; fb[t] = ub.h;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {                       // eight k-steps of 4 rows
+                const int row = 4 * s + lg;
+                const int kx = (row & 3) << 2;                  // = lg << 2
+                float fa[4], fb[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ca = wm * 64 + t * 16 + li, cb = wn * 64 + t * 16 + li;
+                    fa[t] = *reinterpret_cast<const float*>(sa + row * ROWB + (((ca >> 2) ^ kx) << 4) + ((ca & 3) << 2));
+                    fb[t] = *reinterpret_cast<const float*>(sb + row * ROWB + (((cb >> 2) ^ kx) << 4) + ((cb & 3) << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (kt_lo < kt_hi) {
+        issue(kt_lo, 0);
+        __syncthreads();
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            const int cur = (kt - kt_lo) & 1;
+            if (kt + 1 < kt_hi) issue(kt + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: 16x16 MFMA C/D layout: col = lane&15, row = (lane>>4)*4 + reg.  Stage through LDS (64 KiB).
+    float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + i * 16 + lg * 4 + r;
+                const int col = wn * 64 + j * 16 + li;
+                stage[row * BT + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int c8 = tid & 15, rbase = tid >> 4;
+    const int n = n0 + c8 * 8;
+    if (n >= p.N) return;
+    if (p.splitk > 1) {
+        float* part = p.splitk_ws + ((size_t)z * p.splitk + blockIdx.y) * (size_t)p.M * p.N;
+#pragma unroll 1
+        for (int u = 0; u < 8; ++u) {
+            const int row = rbase + u * 16, m = m0 + row;
+            if (m < p.M) {
+                *reinterpret_cast<f32x4*>(part + (size_t)m * p.N + n) = *reinterpret_cast<const f32x4*>(stage + row * BT + c8 * 8);
+                *reinterpret_cast<f32x4*>(part + (size_t)m * p.N + n + 4) = *reinterpret_cast<const f32x4*>(stage + row * BT + c8 * 8 + 4);
+            }
+        }
+        return;
+    }
+    const bool vec = p.vec_epi != 0;
+    const int cnt = min(8, p.N - n);
+#pragma unroll 1
+    for (int u = 0; u < 8; ++u) {
+        const int row = rbase + u * 16, m = m0 + row;
+        if (m >= p.M) continue;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BT + c8 * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BT + c8 * 8 + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        epi_apply(p, z, m, n, v, cnt, vec);
+    }
+}
+
+}  // namespace
+
+int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
+    GemmArgs a = a_in;
+    const int epc = dtype == SQ_BF16 ? 8 : 4;
+    SQ_REQUIRE(dtype == SQ_BF16 || dtype == SQ_F32, "gemm_tn: dtype %d", dtype);
+    SQ_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm_tn: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    // M may be ragged: A columns in [M, round_up(M, 8)) are read (they must exist: lda >= round_up(M, 8)) but
+    // the corresponding output rows are never written
+    SQ_REQUIRE(a.N % 8 == 0 && a.lda >= (a.M + 7) / 8 * 8, "gemm_tn: N=%d must be a multiple of 8 and lda=%d >= round_up(M=%d, 8)", a.N, a.lda, a.M);
+    SQ_REQUIRE(a.lda % epc == 0 && a.ldb % epc == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 &&
+               (a.sA % epc) == 0 && (a.sB % epc) == 0, "gemm_tn: operands must be 16-byte aligned (lda=%d ldb=%d)", a.lda, a.ldb);
+    SQ_REQUIRE(a.a_bytes > 0 && a.a_bytes < (1ull << 31) && a.b_bytes > 0 && a.b_bytes < (1ull << 31), "gemm_tn: operand extents must be < 2 GiB");
+    SQ_REQUIRE(!a.conv, "gemm_tn: no convolution view");
+    {
+        auto al = [](const void* ptr, int ld, long long st, int elem) {
+            return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
+        };
+        bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, 4) &&
+                  al(a.gelu_grad_of, a.ldgg, a.sGg, 4) && al(a.C2, a.ldc2, a.sC2, 2);
+        ok = ok && al(a.C, a.ldc, a.sC, a.out_dtype == SQ_F32 ? 4 : 2) && al(a.res, a.ldres, a.sRes, a.res_dtype == SQ_F32 ? 4 : 2);
+        a.vec_epi = ok ? 1 : 0;
+    }
+    const int kr = dtype == SQ_BF16 ? 64 : 32;
+    const int nk = (a.K + kr - 1) / kr;
+    const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    a.splitk = 1;
+    if (a.splitk_ws && tiles * a.batch < 256 && nk >= 4) {
+        long long s = (512 + tiles * a.batch - 1) / (tiles * a.batch);
+        if (s > nk / 2) s = nk / 2;
+        if (s > 32) s = 32;
+        while (s > 1 && (size_t)s * a.M * a.N * a.batch * sizeof(float) > a.splitk_ws_bytes) --s;
+        if (s > 1) a.splitk = (int)s;
+    }
+    int prof = -1;
+    if (sq_prof_on()) {
+        const double es = dtype == SQ_BF16 ? 2.0 : 4.0;
+        char name[96];
+        snprintf(name, sizeof(name), "gemmtn_%s_M%d_N%d_K%d_b%d", dtype == SQ_BF16 ? "bf16" : "f32", a.M, a.N, a.K, a.batch);
+        prof = sq_prof_begin(name, 2.0 * a.M * (double)a.N * a.K * a.batch,
+                             ((double)a.K * (a.M + a.N) * es + (double)a.M * a.N * 4.0) * a.batch, stream);
+    }
+    dim3 grid((unsigned)tiles, a.splitk, a.batch), block(256);
+    if (dtype == SQ_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, block, 65536, stream, a);
+    else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 65536, stream, a);
+    SQ_LAUNCH_CHECK();
+    int rc = SQ_OK;
+    if (a.splitk > 1) rc = sq_launch_splitk_reduce(a, stream);
+    if (prof >= 0) sq_prof_end(prof, stream);
+    return rc;
+}

@@ -33,12 +33,12 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-__global__ void mse_final_kernel(const double* __restrict__ partial, int nblk, double inv_n, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nblk; ++i) s += partial[i];
-        *loss = (float)(s * inv_n);
-    }
+__global__ __launch_bounds__(256) void mse_final_kernel(const double* __restrict__ partial, int nblk, double inv_n, float* __restrict__ loss) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += partial[i];
+    s = block_sum_f64(s, sh);
+    if (threadIdx.x == 0) *loss = (float)(s * inv_n);
 }
 
 // torch.optim.AdamW(amsgrad=False) single-tensor update (main.py:180-183), fp32 state
@@ -92,10 +92,12 @@ __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ 
     s = block_sum_f64(ae, sh);    if (threadIdx.x == 0) partial[blockIdx.x * 3 + 2] = s;
 }
 
-__global__ void metrics_final_kernel(const double* __restrict__ partial, int nblk, double inv_bg, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double rs = 0.0, rc = 0.0, ae = 0.0;
-        for (int i = 0; i < nblk; ++i) { rs += partial[i * 3]; rc += partial[i * 3 + 1]; ae += partial[i * 3 + 2]; }
+__global__ __launch_bounds__(256) void metrics_final_kernel(const double* __restrict__ partial, int nblk, double inv_bg, float* __restrict__ out) {
+    __shared__ double sh[4];
+    double rs = 0.0, rc = 0.0, ae = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) { rs += partial[i * 3]; rc += partial[i * 3 + 1]; ae += partial[i * 3 + 2]; }
+    rs = block_sum_f64(rs, sh); rc = block_sum_f64(rc, sh); ae = block_sum_f64(ae, sh);
+    if (threadIdx.x == 0) {
         out[0] = (float)(ae * inv_bg);          // MAE
         out[1] = (float)(rs / rc);              // mean Pearson over valid genes (NaN when none, as np.mean([]))
         out[2] = (float)rc;                     // number of genes that entered the mean
@@ -118,7 +120,7 @@ extern "C" int sq_mse_loss_grad(const float* pred, const float* target, size_t n
     if (nb > RED_BLOCKS) nb = RED_BLOCKS;
     hipLaunchKernelGGL(mse_kernel, dim3((int)nb), dim3(256), 0, st, pred, target, n, grad_scale, grad, (double*)scratch);
     SQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, (const double*)scratch, (int)nb, 1.0 / (double)n, loss_out);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, (const double*)scratch, (int)nb, 1.0 / (double)n, loss_out);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
@@ -146,7 +148,7 @@ extern "C" int sq_batch_metrics(const float* pred, const float* target, int B, i
     const int nb = (G + 255) / 256;
     hipLaunchKernelGGL(metrics_kernel, dim3(nb), dim3(256), 0, st, pred, target, B, G, (double*)scratch);
     SQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(64), 0, st, (const double*)scratch, nb, 1.0 / ((double)B * G), out3);
+    hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(256), 0, st, (const double*)scratch, nb, 1.0 / ((double)B * G), out3);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }

@@ -2,9 +2,9 @@
 // optionally of the input tokens, from d(loss)/d(out).  Replaces torch autograd over
 // src/tformer_lin.py in the training loop src/vit.py:163-180.
 //
-// Every matrix product is an NT GEMM on the MFMA engine.  "dX = dY . W" products read a transposed
-// copy of the weight; "dW = dY^T . X" products read transposed (zero-padded to 8 columns) copies of
-// both activations.  Transposes are explicit memory-bound kernels in this version.
+// "dX = dY . W" products are NT GEMMs on a transposed copy of the (small) weight; "dW = dY^T . X"
+// products contract over tokens and run on the TN kernel straight from the token-major activations
+// the forward pass saved (no transposed activation copies).
 #include "elementwise.h"
 #include "gemm.h"
 #include "vis.h"
@@ -19,13 +19,10 @@ struct BwdBufs {
     void* dP;                        // [M, HD] T
     float* dLf;                      // [M, HD] f32
     void* dF;                        // [M, HD] T
-    void* t1; void* t2;              // [max(D,HD), Mp] T transposes
     void* wT;                        // [max(D,HD) * max(D,HD)] T transposed weight
     void* wcT;                       // [H, 64, 64] T
     float* dCs; void* dCs_lp; float* dTs; void* dSm; float* dXbar;   // [B, HD] / [B, D]
-    void* s1; void* s2;              // [max(D,HD), Bp] T
     void* dout_lp;                   // [B, Gp] T
-    void* doutT;                     // [G, Bp] T
     void* whT;                       // [D, Gp] T
     float* dxn; float* dxm;          // [B, D]
     float* red_ws;                   // reduction scratch
@@ -38,7 +35,7 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
     const size_t es = sq_dtype_size(dtype);
     const bool lp = dtype == SQ_BF16;
     const size_t M = (size_t)B * c.num_clusters, D = c.input_dim, HD = (size_t)c.nheads * SQ_HEAD_DIM, G = c.num_outputs;
-    const size_t Mp = sq_align_up(M, 8), Bp = sq_align_up(B, 8), Gp = sq_align_up(G, 8);
+    const size_t Gp = sq_align_up(G, 8);
     const size_t W = D > HD ? D : HD;
     o->dXa = (float*)a.take(M * D * 4); o->dXa_lp = lp ? a.take(M * D * 2) : (void*)o->dXa;
     o->dXb = (float*)a.take(M * D * 4); o->dXb_lp = lp ? a.take(M * D * 2) : (void*)o->dXb;
@@ -47,16 +44,13 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
     o->dP = a.take(M * HD * es);
     o->dLf = (float*)a.take(M * HD * 4);
     o->dF = a.take(M * HD * es);
-    o->t1 = a.take(W * Mp * es); o->t2 = a.take(W * Mp * es);
     o->wT = a.take(W * W * es);
     o->wcT = a.take((size_t)c.nheads * 64 * 64 * es);
     o->dCs = (float*)a.take((size_t)B * HD * 4); o->dCs_lp = lp ? a.take((size_t)B * HD * 2) : (void*)o->dCs;
     o->dTs = (float*)a.take((size_t)B * HD * 4);
     o->dSm = a.take((size_t)B * HD * es);
     o->dXbar = (float*)a.take((size_t)B * D * 4);
-    o->s1 = a.take(W * Bp * es); o->s2 = a.take(W * Bp * es);
     o->dout_lp = a.take((size_t)B * Gp * es);
-    o->doutT = a.take(G * Bp * es);
     o->whT = a.take(D * Gp * es);
     o->dxn = (float*)a.take((size_t)B * D * 4); o->dxm = (float*)a.take((size_t)B * D * 4);
     size_t red = sq_ln_bwd_ws_floats((int)W);
@@ -98,7 +92,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
     }
     const int N = c->num_clusters, D = c->input_dim, H = c->nheads, HD = H * SQ_HEAD_DIM, G = c->num_outputs;
     const int M = B * N;
-    const int Mp = (int)sq_align_up(M, 8), Bp = (int)sq_align_up(B, 8), Gp = (int)sq_align_up(G, 8);
+    const int Gp = (int)sq_align_up(G, 8);
     const int es = sq_dtype_size(dtype);
     const bool lp = dtype == SQ_BF16;
     const char* wbase = lp ? (const char*)params_lp : (const char*)params;
@@ -116,6 +110,15 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         g.splitk_ws = b.skws; g.splitk_ws_bytes = b.skws_bytes;
         return g;
     };
+    // C[M_,N_] (f32, ldc) = sum_k A[k, 0:M_] * Bm[k, 0:N_]   (token-major operands, K_ rows)
+    auto gemm_tn = [&](const void* A, int lda, const void* Bm, int ldb, float* C, int ldc, int M_, int N_, int K_) {
+        GemmArgs g;
+        g.A = A; g.lda = lda; g.a_bytes = (size_t)K_ * lda * es;
+        g.B = Bm; g.ldb = ldb; g.b_bytes = (size_t)K_ * ldb * es;
+        g.C = C; g.ldc = ldc; g.M = M_; g.N = N_; g.K = K_;
+        g.splitk_ws = b.skws; g.splitk_ws_bytes = b.skws_bytes;
+        return g;
+    };
     auto tr = [&](const void* src, int lds_, void* dst, int ldd, int R, int C) {
         return sq_k_transpose(src, lds_, dst, ldd, R, C, es, 1, 0, 0, st);
     };
@@ -123,9 +126,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
 
     // ---------------- head: out = LN(mean_n X) Wh^T + bh ----------------
     RUN(sq_k_cast_pad(grad_out, G, b.dout_lp, dtype, Gp, B, G, st));
-    RUN(tr(b.dout_lp, Gp, b.doutT, Bp, B, G));
-    RUN(tr(w.xn, D, b.s2, Bp, B, D));
-    { GemmArgs g = gemm(b.doutT, Bp, b.s2, Bp, Gp_(lay.head_w), D, G, D, Bp); RUN(sq_launch_gemm(g, dtype, st)); }
+    { GemmArgs g = gemm_tn(b.dout_lp, Gp, w.xn, D, Gp_(lay.head_w), D, G, D, B); RUN(sq_launch_gemm_tn(g, dtype, st)); }
     RUN(sq_k_colsum(grad_out, SQ_F32, B, G, G, b.red_ws, Gp_(lay.head_b), st));
     RUN(tr(W(lay.head_w), D, b.whT, Gp, G, D));
     { GemmArgs g = gemm(b.dout_lp, Gp, b.whT, Gp, b.dxn, D, B, D, Gp); RUN(sq_launch_gemm(g, dtype, st)); }
@@ -139,9 +140,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
     for (int l = c->depth - 1; l >= 0; --l) {
         const sq_vis_layer_offsets& L = lay.layer[l];
         // ---------------- FeedForward: X2 = GELU(LN(X1) W1^T + b1) W2^T + b2 + X1 ----------------
-        RUN(tr(dXcur_lp, D, b.t1, Mp, M, D));
-        RUN(tr(w.H1[l], D, b.t2, Mp, M, D));
-        { GemmArgs g = gemm(b.t1, Mp, b.t2, Mp, Gp_(L.ff2_w), D, D, D, Mp); RUN(sq_launch_gemm(g, dtype, st)); }
+        { GemmArgs g = gemm_tn(dXcur_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         RUN(sq_k_colsum(dXcur, SQ_F32, M, D, D, b.red_ws, Gp_(L.ff2_b), st));
         RUN(tr(W(L.ff2_w), D, b.wT, D, D, D));
         {   // dU = (dX2 . W2) * GELU'(U)
@@ -149,9 +148,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
             g.C = b.dU; g.out_dtype = dtype; g.gelu_grad_of = w.U[l]; g.ldgg = D;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        RUN(tr(b.dU, D, b.t1, Mp, M, D));
-        RUN(tr(w.Y[l], D, b.t2, Mp, M, D));
-        { GemmArgs g = gemm(b.t1, Mp, b.t2, Mp, Gp_(L.ff1_w), D, D, D, Mp); RUN(sq_launch_gemm(g, dtype, st)); }
+        { GemmArgs g = gemm_tn(b.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         RUN(sq_k_colsum(b.dU, dtype, M, D, D, b.red_ws, Gp_(L.ff1_b), st));
         RUN(tr(W(L.ff1_w), D, b.wT, D, D, D));
         { GemmArgs g = gemm(b.dU, D, b.wT, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
@@ -161,9 +158,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         float* dX1 = dXoth; void* dX1_lp = dXoth_lp;
 
         // ---------------- projection: X1 = O Wp^T + bp + X ----------------
-        RUN(tr(dX1_lp, D, b.t1, Mp, M, D));
-        RUN(tr(w.O[l], HD, b.t2, Mp, M, HD));
-        { GemmArgs g = gemm(b.t1, Mp, b.t2, Mp, Gp_(L.proj_w), HD, D, HD, Mp); RUN(sq_launch_gemm(g, dtype, st)); }
+        { GemmArgs g = gemm_tn(dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         RUN(sq_k_colsum(dX1, SQ_F32, M, D, D, b.red_ws, Gp_(L.proj_b), st));
         RUN(tr(W(L.proj_w), HD, b.wT, D, D, HD));                 // Wp [D, HD] -> [HD, D]
         {   // dP = (dX1 . Wp) * GELU'(P)
@@ -182,13 +177,10 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        RUN(tr(b.dP, HD, b.t1, Mp, M, HD));
-        RUN(tr(w.Lf[l], HD, b.t2, Mp, M, HD));
         {   // dWc_h[:, :64] = dP_h^T . Lf_h
-            GemmArgs g = gemm(b.t1, Mp, b.t2, Mp, Gp_(L.c_w), 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, Mp);
-            g.a_bytes = (size_t)HD * Mp * es; g.b_bytes = (size_t)HD * Mp * es;
-            g.batch = H; g.sA = (long long)SQ_HEAD_DIM * Mp; g.sB = (long long)SQ_HEAD_DIM * Mp; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
-            RUN(sq_launch_gemm(g, dtype, st));
+            GemmArgs g = gemm_tn(b.dP, HD, w.Lf[l], HD, Gp_(L.c_w), 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, M);
+            g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
+            RUN(sq_launch_gemm_tn(g, dtype, st));
         }
         // ---------------- summary branch ----------------
         if (lp) RUN(sq_k_cast_pad(b.dCs, HD, b.dCs_lp, dtype, HD, B, HD, st));
@@ -200,19 +192,14 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        RUN(tr(b.dCs_lp, HD, b.s1, Bp, B, HD));
-        RUN(tr(w.Ts[l], HD, b.s2, Bp, B, HD));
         {   // dWc_h[:, 64:] = dCs_h^T . Ts_h
-            GemmArgs g = gemm(b.s1, Bp, b.s2, Bp, Gp_(L.c_w) + SQ_HEAD_DIM, 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, Bp);
-            g.a_bytes = (size_t)HD * Bp * es; g.b_bytes = (size_t)HD * Bp * es;
-            g.batch = H; g.sA = (long long)SQ_HEAD_DIM * Bp; g.sB = (long long)SQ_HEAD_DIM * Bp; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
-            RUN(sq_launch_gemm(g, dtype, st));
+            GemmArgs g = gemm_tn(b.dCs_lp, HD, w.Ts[l], HD, Gp_(L.c_w) + SQ_HEAD_DIM, 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, B);
+            g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
+            RUN(sq_launch_gemm_tn(g, dtype, st));
         }
         RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), b.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), b.red_ws, B, HD, st));
         RUN(sq_k_colsum(b.dSm, dtype, B, HD, HD, b.red_ws, Gp_(L.s_b), st));
-        RUN(tr(b.dSm, HD, b.s1, Bp, B, HD));
-        RUN(tr(w.Xbar[l], D, b.s2, Bp, B, D));
-        { GemmArgs g = gemm(b.s1, Bp, b.s2, Bp, Gp_(L.s_w), D, HD, D, Bp); RUN(sq_launch_gemm(g, dtype, st)); }
+        { GemmArgs g = gemm_tn(b.dSm, HD, w.Xbar[l], D, Gp_(L.s_w), D, HD, D, B); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         RUN(tr(W(L.s_w), D, b.wT, HD, HD, D));                    // Ws [HD, D] -> [D, HD]
         {   // dXbar / N   (Xbar = mean_n X: every token of the slide receives dXbar / N)
             GemmArgs g = gemm(b.dSm, HD, b.wT, HD, b.dXbar, D, B, D, HD);
@@ -222,9 +209,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         // ---------------- local branch ----------------
         RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), b.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.red_ws, M, HD, st));
         RUN(sq_k_colsum(b.dF, dtype, M, HD, HD, b.red_ws, Gp_(L.f_b), st));
-        RUN(tr(b.dF, HD, b.t1, Mp, M, HD));
-        RUN(tr(w.Xin_lp[l], D, b.t2, Mp, M, D));
-        { GemmArgs g = gemm(b.t1, Mp, b.t2, Mp, Gp_(L.f_w), D, HD, D, Mp); RUN(sq_launch_gemm(g, dtype, st)); }
+        { GemmArgs g = gemm_tn(b.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         RUN(tr(W(L.f_w), D, b.wT, HD, HD, D));                    // Wf [HD, D] -> [D, HD]
         {   // dXin = dF . Wf + dX1 (residual) + dXbar/N (per-slide row bias)
             GemmArgs g = gemm(b.dF, HD, b.wT, HD, dXcur, D, M, D, HD);

@@ -92,6 +92,29 @@ def test_split_k_path(M, N, K, dtype):
     assert torch.equal(out, out2)                      # fixed reduction order -> bitwise repeatable
 
 
+@pytest.mark.parametrize("T,NO,NI", [(6400, 1024, 1024), (64, 1024, 2048), (200, 20820, 128), (333, 64, 64), (1000, 136, 264)])
+@pytest.mark.parametrize("dtype", [_lib.SQ_F32, _lib.SQ_BF16])
+@pytest.mark.parametrize("ws_bytes", [0, 64 << 20])
+def test_weight_grad_tn_kernel(T, NO, NI, dtype, ws_bytes):
+    """dW = dY^T . X straight from token-major operands (TN kernel), ragged token counts and output rows."""
+    _lib.require_gpu()
+    g = torch.Generator().manual_seed(T + NO + NI)
+    dY = to_bf16_f32(torch.randn(T, NO, generator=g))
+    X = to_bf16_f32(torch.randn(T, NI, generator=g) + torch.arange(NI)[None, :] * 1e-3)      # asymmetric columns
+    tdt = torch.bfloat16 if dtype == _lib.SQ_BF16 else torch.float32
+    ldy = (NO + 7) // 8 * 8
+    dYd = torch.zeros(T, ldy, dtype=tdt, device="cuda")
+    dYd[:, :NO] = dY.to(tdt)
+    Xd = X.to("cuda", tdt).contiguous()
+    dW = torch.full((NO, NI), float("nan"), device="cuda")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda") if ws_bytes else None
+    _lib.check(_lib.lib().sq_linear_weight_grad(dtype, _lib.ptr(dYd), ldy, _lib.ptr(Xd), NI, _lib.ptr(dW), NI, NO, NI, T,
+                                                _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = dY.double().T @ X.double()
+    assert rel_err(dW.cpu(), ref) < 1e-5, rel_err(dW.cpu(), ref)
+
+
 def test_bad_arguments_fail_loudly():
     _lib.require_gpu()
     A = torch.zeros(4, 6, device="cuda")
