@@ -1,0 +1,82 @@
+"""Patch features -- counterpart of /root/reference/pre_processing/compute_features_hdf5.py (same flags,
+same files: reads ``<patch_data_path>/<slide>/<slide>.hdf5`` (one uint8 [S,S,3] dataset per tile), writes
+``<feature_path>/<project>/<WSI>/<WSI>.h5`` dataset ``"{feat_type}_features"`` [n, 2048] fp32 and
+``complete_tile.txt``).  The per-patch batch-1 loop with two PCIe syncs per patch (:116-123) becomes one
+upload of the slide's patches and batched HIP ResNet-50 launches with the transform fused.
+
+    python -m sequoia_pub_amd.cli.compute_features --feat_type resnet --ref_file ref.csv \
+        --patch_data_path Patches_hdf5 --feature_path features [--start i --end j]
+Under torchrun the slide list is sharded across the GPUs (the reference's --start/--end, automatically)."""
+import argparse
+import os
+import random
+
+import numpy as np
+import torch
+
+from .. import store
+from ..data import shard_rows
+from ..resnet import resnet50
+from .common import init_distributed, ref_frame, seed_everything
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='Getting features')
+    parser.add_argument('--feat_type', default="resnet", type=str, required=True, help='"resnet" (the "uni" ViT-L extractor needs timm + gated weights: not available)')
+    parser.add_argument('--ref_file', type=str, required=True, help='Path with reference csv file')
+    parser.add_argument('--patch_data_path', type=str, required=True, help='Directory where the patch is saved')
+    parser.add_argument('--feature_path', type=str, default="/examples/features", help='Output directory to save features')
+    parser.add_argument('--max_patch_number', type=int, default=4000, help='Max number of patches to use per slide')
+    parser.add_argument('--seed', type=int, default=99, help='Seed for random generation')
+    parser.add_argument("--tcga_projects", help="the tcga_projects we want to use", default=None, type=str, nargs='*')
+    parser.add_argument('--start', type=int, default=0, help='Start slide index for parallelization')
+    parser.add_argument('--end', type=int, default=None, help='End slide index for parallelization')
+    parser.add_argument('--compute_dtype', default='fp32', choices=['fp32', 'bf16'])
+    parser.add_argument('--weights', type=str, default=None, help='torchvision resnet50 state_dict (.pth); default: model_zoo URL')
+    args = parser.parse_args(argv)
+    seed_everything(args.seed)
+    rank, world, device = init_distributed()
+    if args.feat_type != 'resnet':
+        raise SystemExit('feat_type "uni" (timm vit_large_patch16_224 + gated UNI weights) is not available in this build')
+    model = resnet50(pretrained=args.weights is None, compute_dtype=args.compute_dtype)
+    if args.weights:
+        model.load_state_dict(torch.load(args.weights, map_location='cpu'))
+    model.to(device).eval()
+    df = ref_frame(args.ref_file, args.tcga_projects, args.start, args.end)
+    lo, hi = shard_rows(df.shape[0], rank, world)
+    df = df.iloc[lo:hi]
+    print(f'Number of slides = {df.shape[0]} (rank {rank}/{world})')
+    for _, row in df.iterrows():
+        WSI = row['wsi_file_name']
+        WSI_slide = WSI.split('.')[0]
+        project = row['tcga_project']
+        WSI = WSI.replace('.svs', '')
+        if not os.path.exists(os.path.join(args.patch_data_path, WSI_slide)):
+            print('Not exist {}'.format(os.path.join(args.patch_data_path, WSI_slide)))
+            continue
+        path = os.path.join(args.patch_data_path, WSI_slide, WSI_slide + '.hdf5')
+        path_h5 = os.path.join(args.feature_path, project, WSI)
+        os.makedirs(path_h5, exist_ok=True)
+        if os.path.exists(os.path.join(path_h5, "complete_resnet.txt")):     # (sic) the reference checks this name
+            print(f'{WSI}: Resnet features already obtained')
+            continue
+        try:
+            with store.File(path, 'r') as f_read:
+                keys = list(f_read.keys())
+                if len(keys) > args.max_patch_number:
+                    keys = random.sample(keys, args.max_patch_number)
+                patches = np.stack([np.asarray(f_read[key][:]) for key in keys])
+            feats = model.extract_patches_u8(torch.from_numpy(patches), sub_batch=128).cpu().numpy()
+            f_write = store.File(os.path.join(path_h5, WSI + '.h5'), "w")
+            f_write.create_dataset(f"{args.feat_type}_features", data=feats)
+            f_write.close()
+            with open(os.path.join(path_h5, "complete_tile.txt"), 'w') as f_sum:
+                f_sum.write(f"Total n patch = {len(feats)}")
+        except Exception as e:                                               # :141-144 skip the slide, keep going
+            print(e)
+            print(WSI)
+            continue
+
+
+if __name__ == '__main__':
+    main()
