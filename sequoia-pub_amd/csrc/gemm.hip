@@ -55,7 +55,7 @@ template <> struct Mma<bf16_t> {
     }
 };
 
-template <typename T, int WTM, int WTN, bool CONV>
+template <typename T, int WTM, int WTN, bool CONV, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     const int e_cnt = min(8, p.N - e_n);
     const bool e_vec = p.vec_epi != 0 && e_cnt == 8 && p.splitk == 1;
     const bool pre16 = e_vec && p.res != nullptr && p.res_dtype == SQ_BF16;
+#pragma clang diagnostic ignored "-Wunused-variable"
     u32x4 rr16[ITER];
     float bias8[8];
     if (pre16) {
@@ -268,30 +269,123 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         return;
     }
     if (e_cnt <= 0) return;
-    // vmcnt counts stores as well as loads, so a global load issued after a store waits for that store's
-    // write acknowledgement: bias / bf16 residual were fetched before the K loop; the other optional
-    // operands (fp32 residual, row bias, GELU' source) are still read inside epi_apply.
-    const bool vec = p.vec_epi != 0;
-#pragma unroll
-    for (int u = 0; u < ITER; ++u) {
-        const int row = e_rbase + u * RPI;
-        const int m = m0 + row;
-        if (m < p.M) {
+    if (!e_vec) {           // ragged N / unaligned operands: generic element-wise path (rolled loop)
+#pragma unroll 1
+        for (int u = 0; u < ITER; ++u) {
+            const int row = e_rbase + u * RPI;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8 + 4);
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            float rv[8];
+            epi_apply<EPI>(p, z, m, e_n, v, e_cnt, false);
+        }
+        return;
+    }
+    // Fast path.  vmcnt counts stores as well as loads, so a global load issued after a store waits for that
+    // store's write acknowledgement: bias and the bf16 residual were fetched before the K loop, and the
+    // remaining optional operands (fp32 residual, row bias, GELU' source) are fetched for a whole group of
+    // U rows BEFORE that group's first store.
+    const float* res32 = (p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
+    const float* rowbias = p.rowbias ? p.rowbias + (long long)z * p.sRb : nullptr;
+    const float* gg = p.gelu_grad_of ? p.gelu_grad_of + (long long)z * p.sGg : nullptr;
+    float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
+    bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
+    bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
+    float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
+    constexpr int U = ITER < 4 ? ITER : 4;
+#pragma unroll
+    for (int c0 = 0; c0 < ITER; c0 += U) {
+        float aux[U][8];     // gg mode: the GELU' source values; otherwise fp32 residual + row bias
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) aux[u][e] = 0.f;
+        if ((EPI & 2) && gg) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int m = m0 + e_rbase + (c0 + u) * RPI;
+                if (m < p.M) {
+                    const float* src = gg + (long long)m * p.ldgg + e_n;
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { aux[u][e] = t0[e]; aux[u][4 + e] = t1[e]; }
+                }
+            }
+        } else {
+            if (res32) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int m = m0 + e_rbase + (c0 + u) * RPI;
+                    if (m < p.M) {
+                        const float* src = res32 + (long long)m * p.ldres + e_n;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { aux[u][e] = t0[e]; aux[u][4 + e] = t1[e]; }
+                    }
+                }
+            }
+            if (rowbias) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int m = m0 + e_rbase + (c0 + u) * RPI;
+                    if (m < p.M) {
+                        const float* src = rowbias + (long long)(m / p.rows_per_group) * p.ldrb + e_n;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { aux[u][e] += t0[e]; aux[u][4 + e] += t1[e]; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = e_rbase + (c0 + u) * RPI;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8 + 4);
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = p.alpha * v[e] + (pre_b ? bias8[e] : 0.f);
             if (pre16) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { rv[2 * e] = __uint_as_float(rr16[u][e] << 16); rv[2 * e + 1] = __uint_as_float(rr16[u][e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rr16[c0 + u][e] << 16); v[2 * e + 1] += __uint_as_float(rr16[c0 + u][e] & 0xffff0000u); }
             }
-            epi_apply(p, z, m, e_n, v, e_cnt, vec, pre16 ? rv : nullptr, pre_b ? bias8 : nullptr);
+            if (!((EPI & 2) && gg)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += aux[u][e];
+            }
+            if (cpre) {
+                float* d = cpre + (long long)m * p.ldpre + e_n;
+                *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+            if ((EPI & 1) && p.act == SQ_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            } else if (p.act == SQ_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if ((EPI & 2) && gg) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(aux[u][e]);
+            }
+            if (c32) {
+                float* d = c32 + (long long)m * p.ldc + e_n;
+                *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+            const u32x4 h = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            if (c16p) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = h;
+            if (c2) *reinterpret_cast<u32x4*>(c2 + (long long)m * p.ldc2 + e_n) = h;
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep iterations from being interleaved (register pressure)
     }
 }
 
 // sums the K-slice partials in slice order, then the normal epilogue (N % 8 == 0 enforced by the launcher)
+template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int N8 = p.N / 8;
     const size_t total = (size_t)p.M * N8;
@@ -309,8 +403,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             s1[0] += t1[0]; s1[1] += t1[1]; s1[2] += t1[2]; s1[3] += t1[3];
         }
         float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        epi_apply(p, z, m, n, v, 8, vec);
+        epi_apply<EPI>(p, z, m, n, v, 8, vec);
     }
+}
+
+int launch_reduce(const GemmArgs& a, hipStream_t stream) {
+    size_t nb = ((size_t)a.M * (a.N / 8) + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    const dim3 grid((int)nb, 1, a.batch), block(256);
+    if (a.act == SQ_ACT_GELU || a.gelu_grad_of) hipLaunchKernelGGL(splitk_reduce_kernel<3>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<0>, grid, block, 0, stream, a);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+template <typename T, int WTM, int WTN, bool CONV>
+int launch_epi(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    const dim3 block(256);
+    if (a.splitk > 1) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, CONV, 0>), grid, block, lds, stream, a);   // partials only
+    else if (a.gelu_grad_of) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, CONV, 2>), grid, block, lds, stream, a);
+    else if (a.act == SQ_ACT_GELU) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, CONV, 1>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, CONV, 0>), grid, block, lds, stream, a);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
 }
 
 template <typename T, int WTM, int WTN>
@@ -318,16 +433,9 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * (BM + BN) * 128;
-    dim3 grid(tiles, a.splitk, a.batch), block(256);
-    if (a.conv) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, false>), grid, block, lds, stream, a);
-    SQ_LAUNCH_CHECK();
-    if (a.splitk > 1) {
-        size_t nb = ((size_t)a.M * (a.N / 8) + 255) / 256;
-        if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb, 1, a.batch), dim3(256), 0, stream, a);
-        SQ_LAUNCH_CHECK();
-    }
+    const dim3 grid(tiles, a.splitk, a.batch);
+    if (int e = a.conv ? launch_epi<T, WTM, WTN, true>(a, grid, lds, stream) : launch_epi<T, WTM, WTN, false>(a, grid, lds, stream)) return e;
+    if (a.splitk > 1) return launch_reduce(a, stream);
     return SQ_OK;
 }
 
@@ -343,8 +451,10 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
     // faster than shrinking the tile); narrow problems take the matching 64-wide tile
     int tile;
     const bool can_split = a.splitk_ws != nullptr && a.K >= 16 * 8 * epc;
+    const int nk_tiles = (a.K + 8 * epc - 1) / (8 * epc);
     if (a.N <= 64) tile = blocks(128, 64) >= 256 ? 21 : 11;
     else if (a.M <= 64) tile = blocks(64, 128) >= 256 ? 12 : 11;
+    else if (nk_tiles <= 4 && blocks(128, 64) >= 1024) tile = 21;    // short-K (memory-bound) products: 48 KiB LDS -> 3 blocks/CU
     else if (blocks(128, 128) >= 256 || can_split) tile = 22;
     else tile = 11;
     if (g_force_tile) tile = g_force_tile;
@@ -369,13 +479,7 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
 
 }  // namespace
 
-int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) {
-    size_t nb = ((size_t)a.M * (a.N / 8) + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb, 1, a.batch), dim3(256), 0, stream, a);
-    SQ_LAUNCH_CHECK();
-    return SQ_OK;
-}
+int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return launch_reduce(a, stream); }
 
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;

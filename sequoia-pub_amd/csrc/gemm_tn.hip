@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BT + c8 * 8);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BT + c8 * 8 + 4);
         float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        epi_apply(p, z, m, n, v, cnt, vec);
+        epi_apply<3>(p, z, m, n, v, cnt, vec);
     }
 }
 

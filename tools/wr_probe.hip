@@ -5,9 +5,11 @@
 #include <cstdint>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+extern __shared__ char dyn_lds[];
 template <int MODE>
 __global__ __launch_bounds__(256) void wr(uint16_t* __restrict__ C, const uint16_t* __restrict__ R, int M, int N, int tiles_n) {
     const int tid = threadIdx.x;
+    if (MODE & 8) { reinterpret_cast<volatile int*>(dyn_lds)[tid] = tid; __syncthreads(); }
     int t = blockIdx.x;
     if (MODE & 4) {   // xcd remap
         const int nwg = gridDim.x, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
@@ -40,7 +42,7 @@ template <typename F> float timeit(F f, int it = 20) {
 
 int main() {
     const int M = 627200;
-    for (int N : {128, 256, 512}) {
+    for (int N : {256}) {
         uint16_t *C, *R; size_t bytes = (size_t)M * N * 2;
         hipMalloc(&C, bytes); hipMalloc(&R, bytes); hipMemset(R, 1, bytes);
         const int tiles_n = N / 128, nwg = (M / 128) * tiles_n;
@@ -52,6 +54,12 @@ int main() {
         t = timeit([&] { hipLaunchKernelGGL(wr<6>, dim3(nwg), dim3(256), 0, 0, C, R, M, N, tiles_n); }); printf("N=%d tile store nt+remap     %7.1f us %5.2f TB/s\n", N, t, bytes / t / 1e6);
         t = timeit([&] { hipLaunchKernelGGL(wr<1>, dim3(nwg), dim3(256), 0, 0, C, R, M, N, tiles_n); }); printf("N=%d tile load+store         %7.1f us %5.2f TB/s (r+w)\n", N, t, 2 * bytes / t / 1e6);
         t = timeit([&] { hipLaunchKernelGGL(wr<5>, dim3(nwg), dim3(256), 0, 0, C, R, M, N, tiles_n); }); printf("N=%d tile load+store remap   %7.1f us %5.2f TB/s (r+w)\n", N, t, 2 * bytes / t / 1e6);
+        for (int lds : {0, 32768, 65536, 98304}) {
+            t = timeit([&] { hipLaunchKernelGGL(wr<9>, dim3(nwg), dim3(256), lds, 0, C, R, M, N, tiles_n); });
+            printf("N=%d tile load+store, %3d KB LDS/block (%d blocks/CU) %7.1f us %5.2f TB/s (r+w)\n", N, lds / 1024, lds ? 160 * 1024 / lds : 8, t, 2 * bytes / t / 1e6);
+            t = timeit([&] { hipLaunchKernelGGL(wr<8>, dim3(nwg), dim3(256), lds, 0, C, R, M, N, tiles_n); });
+            printf("N=%d tile store only,  %3d KB LDS/block              %7.1f us %5.2f TB/s\n", N, lds / 1024, t, bytes / t / 1e6);
+        }
         hipFree(C); hipFree(R);
     }
     return 0;
