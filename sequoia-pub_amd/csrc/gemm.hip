@@ -234,8 +234,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         __syncthreads();
         for (int kt = kt_lo; kt < kt_hi; ++kt) {
             const int cur = (kt - kt_lo) & 1;
-            if (kt + 1 < kt_hi && !(p.dbg & 2)) issue_loads(kt + 1, cur ^ 1);
-            if (!(p.dbg & 4)) compute(cur);
+            if (kt + 1 < kt_hi) issue_loads(kt + 1, cur ^ 1);
+            compute(cur);
             __syncthreads();
         }
     }

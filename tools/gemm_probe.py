@@ -37,7 +37,7 @@ def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6)):
         for dbg in dbgs:
             lib.sq_dbg_set(0, tile)
             lib.sq_dbg_set(1, dbg)
-            fn = lambda: _lib.check(lib.sq_linear(dtype, _lib.ptr(A), K, _lib.ptr(W), K, None, None, 0, 0, _lib.ptr(C), 0, N, M, N, K, _lib.ptr(WS), WS.numel(), _lib.stream_ptr()))
+            fn = lambda: _lib.check(lib.sq_linear(dtype, _lib.ptr(A), K, _lib.ptr(W), K, None, None, 0, 0, 0, _lib.ptr(C), 0, N, M, N, K, _lib.ptr(WS), WS.numel(), _lib.stream_ptr()))
             t = time_fn(fn)
             print(f"   tile {tile} dbg {dbg}: {t:8.1f} us {flops / t / 1e6:8.1f} TF", flush=True)
     lib.sq_dbg_set(0, 0)
@@ -45,13 +45,11 @@ def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6)):
 
 
 if __name__ == "__main__":
-    probe(6400, 1024, 1024, _lib.SQ_BF16, dbgs=(0, 1, 2, 4))
-    probe(6400, 1024, 1024, _lib.SQ_F32, dbgs=(0,))
-    probe(8192, 8192, 8192, _lib.SQ_BF16, tiles=(22,), dbgs=(0, 1, 2))
-    probe(64, 1024, 1024, _lib.SQ_BF16, tiles=(0, 12, 11), dbgs=(0,))
-    probe(64, 20820, 1024, _lib.SQ_BF16, tiles=(0, 12, 11), dbgs=(0,))
-    probe(1024, 1024, 6400, _lib.SQ_BF16, tiles=(0, 22, 11), dbgs=(0,))
-    probe(802816, 64, 64, _lib.SQ_BF16, tiles=(0, 21, 11), dbgs=(0,))
-    probe(200704, 256, 64, _lib.SQ_BF16, tiles=(0, 22, 11), dbgs=(0,))
-    probe(3136 * 64, 64, 576, _lib.SQ_BF16, tiles=(0,), dbgs=(0,))
-    probe(49 * 64, 2048, 512, _lib.SQ_BF16, tiles=(0, 22, 11), dbgs=(0,))
+    probe(6400, 1024, 1024, _lib.SQ_BF16, dbgs=(0, 1))
+    probe(6400, 1024, 1024, _lib.SQ_F32, tiles=(22, 11), dbgs=(0,))
+    probe(8192, 8192, 8192, _lib.SQ_BF16, tiles=(22,), dbgs=(0, 1))
+    probe(64, 1024, 1024, _lib.SQ_BF16, tiles=(0,), dbgs=(0,))
+    probe(64, 20820, 1024, _lib.SQ_BF16, tiles=(0, 12), dbgs=(0,))
+    probe(1024, 1024, 6400, _lib.SQ_BF16, tiles=(0,), dbgs=(0,))
+    probe(39200, 256, 2304, _lib.SQ_BF16, tiles=(0, 22, 21), dbgs=(0,))
+    probe(9800, 512, 4608, _lib.SQ_BF16, tiles=(0, 22, 11), dbgs=(0,))
