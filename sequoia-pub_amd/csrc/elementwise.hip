@@ -6,8 +6,8 @@ namespace {
 constexpr float LN_EPS = 1e-5f;
 
 __global__ void add_pos_kernel(const float4* __restrict__ x, const float4* __restrict__ pos, float4* __restrict__ X,
-                               uint2* __restrict__ Xh, size_t total4, size_t nd4) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+                               uint2* __restrict__ Xh, uint32_t total4, uint32_t nd4) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
         const float4 a = x[i], p = pos[i % nd4];
         const float4 v = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
         X[i] = v;
@@ -102,11 +102,10 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 // 16 lanes per 64-wide group (4 elements per lane), 4 groups per wave-iteration
 __global__ __launch_bounds__(256) void ln64_gelu_kernel(const float4* __restrict__ x, const float4* __restrict__ g,
                                                         const float4* __restrict__ b, void* __restrict__ y, int out_bf16,
-                                                        size_t ngroups, int C16) {
+                                                        uint32_t ngroups, int C16) {
     const int sub = threadIdx.x & 15;
-    for (size_t grp = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; grp < ngroups;
-         grp += ((size_t)gridDim.x * blockDim.x) >> 4) {
-        const size_t i4 = grp * 16 + sub;           // float4 index
+    for (uint32_t grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; grp < ngroups; grp += (gridDim.x * blockDim.x) >> 4) {
+        const uint32_t i4 = grp * 16 + sub;         // float4 index (32-bit: 64-bit modulo is very slow)
         const float4 v = x[i4];
         float s = (v.x + v.y) + (v.z + v.w);
 #pragma unroll
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(256) void ln64_gelu_kernel(const float4* __restrict
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
         const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
-        const int c4 = (int)(i4 % (size_t)C16);     // float4 column inside the row
+        const int c4 = (int)(i4 % (uint32_t)C16);   // float4 column inside the row
         const float4 gg = g[c4], bb = b[c4];
         float4 o;
         o.x = gelu_erf(a0 * rstd * gg.x + bb.x);
@@ -165,9 +164,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ sr
 }
 
 __global__ void cast_pad_kernel(const float* __restrict__ src, int lds_, void* __restrict__ dst, int out_bf16, int ldd, int R, int C) {
-    const size_t total = (size_t)R * ldd;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / ldd), c = (int)(i - (size_t)r * ldd);
+    const uint32_t total = (uint32_t)R * ldd;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = (int)(i / (uint32_t)ldd), c = (int)(i - (uint32_t)r * ldd);
         const float v = c < C ? src[(size_t)r * lds_ + c] : 0.f;
         if (out_bf16) reinterpret_cast<bf16_t*>(dst)[i] = f32_to_bf16(v);
         else reinterpret_cast<float*>(dst)[i] = v;
@@ -185,7 +184,8 @@ inline int grid_for(size_t work_items, int block, int cap = 256 * 8) {
 
 int sq_k_add_pos(const float* x, const float* pos, float* X, bf16_t* Xh, int B, int N, int D, hipStream_t s) {
     SQ_REQUIRE(D % 4 == 0, "add_pos: D=%d must be a multiple of 4", D);
-    const size_t total4 = (size_t)B * N * D / 4, nd4 = (size_t)N * D / 4;
+    SQ_REQUIRE((size_t)B * N * D / 4 < (1ull << 31), "add_pos: tensor too large for 32-bit indexing");
+    const uint32_t total4 = (uint32_t)((size_t)B * N * D / 4), nd4 = (uint32_t)((size_t)N * D / 4);
     hipLaunchKernelGGL(add_pos_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, s, (const float4*)x, (const float4*)pos,
                        (float4*)X, (uint2*)Xh, total4, nd4);
     SQ_LAUNCH_CHECK();
@@ -215,8 +215,9 @@ int sq_k_ln_rows(const float* x, const float* g, const float* b, void* y, int ou
 
 int sq_k_ln64_gelu(const float* x, const float* g, const float* b, void* y, int out_dtype, int R, int C, hipStream_t s) {
     SQ_REQUIRE(C % 64 == 0, "ln64_gelu: C=%d must be a multiple of 64", C);
-    const size_t ngroups = (size_t)R * (C / 64);
-    hipLaunchKernelGGL(ln64_gelu_kernel, dim3(grid_for(ngroups * 16, 256)), dim3(256), 0, s, (const float4*)x,
+    SQ_REQUIRE((size_t)R * (C / 4) < (1ull << 31), "ln64_gelu: tensor too large for 32-bit indexing");
+    const uint32_t ngroups = (uint32_t)((size_t)R * (C / 64));
+    hipLaunchKernelGGL(ln64_gelu_kernel, dim3(grid_for((size_t)ngroups * 16, 256)), dim3(256), 0, s, (const float4*)x,
                        (const float4*)g, (const float4*)b, y, out_dtype == SQ_BF16, ngroups, C / 4);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
@@ -251,7 +252,7 @@ int sq_k_transpose(const void* src, int lds_, void* dst, int ldd, int R, int C, 
 }
 
 int sq_k_cast_pad(const float* src, int lds_, void* dst, int dst_dtype, int ldd, int R, int C, hipStream_t s) {
-    SQ_REQUIRE(ldd >= C, "cast_pad: ldd=%d < C=%d", ldd, C);
+    SQ_REQUIRE(ldd >= C && (size_t)R * ldd < (1ull << 31), "cast_pad: ldd=%d < C=%d or tensor too large", ldd, C);
     hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for((size_t)R * ldd, 256)), dim3(256), 0, s, src, lds_, dst,
                        dst_dtype == SQ_BF16, ldd, R, C);
     SQ_LAUNCH_CHECK();

@@ -90,11 +90,11 @@ __global__ void group_sum_kernel(const T* __restrict__ x, int G, int N, int C, f
 }
 
 __global__ void bcast_rows_kernel(const float4* __restrict__ src, float scale, float4* __restrict__ dst, uint2* __restrict__ dst_lp,
-                                  int N, int D4, size_t total4) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = i / ((size_t)N * D4);
-        const int d = (int)(i % D4);
-        float4 v = src[b * D4 + d];
+                                  int N, int D4, uint32_t total4) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+        const uint32_t b = i / ((uint32_t)N * D4);
+        const int d = (int)(i % (uint32_t)D4);
+        float4 v = src[(size_t)b * D4 + d];
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
         dst[i] = v;
         if (dst_lp) dst_lp[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
@@ -289,8 +289,9 @@ int sq_k_group_sum(const void* x, int dtype, int G, int N, int C, float scale, f
 
 int sq_k_bcast_rows(const float* src, float scale, float* dst, bf16_t* dst_lp, int B, int N, int D, hipStream_t s) {
     SQ_REQUIRE(D % 4 == 0, "bcast_rows: D=%d", D);
-    const size_t total4 = (size_t)B * N * D / 4;
-    size_t g = (total4 + 255) / 256;
+    SQ_REQUIRE((size_t)B * N * D / 4 < (1ull << 31), "bcast_rows: tensor too large for 32-bit indexing");
+    const uint32_t total4 = (uint32_t)((size_t)B * N * D / 4);
+    size_t g = ((size_t)total4 + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(bcast_rows_kernel, dim3((int)g), dim3(256), 0, s, (const float4*)src, scale, (float4*)dst, (uint2*)dst_lp, N, D / 4, total4);
     SQ_LAUNCH_CHECK();

@@ -22,43 +22,56 @@ constexpr float BN_MEAN[3] = {0.485f, 0.456f, 0.406f};
 constexpr float BN_STD[3] = {0.229f, 0.224f, 0.225f};
 
 // A0[m, k] for conv1: m = (img, oh, ow), k = (kh*7 + kw)*3 + c; zero for padding taps and k >= 147.
-// src_u8: uint8 NHWC (transform fused) or src_f32: fp32 NCHW (already normalised, reference tensor layout)
+// src_u8: uint8 NHWC (transform fused) or src_f32: fp32 NCHW (already normalised, reference tensor layout).
+// The uint8 transform goes through a 3 x 256 look-up table built per block with exactly the reference's
+// fp32 operations (ConvertImageDtype: u8 / 255; Normalize: (x - mean) / std), so results are bit-identical
+// to evaluating the formula per element; tap geometry comes from a 152-entry table.
 template <typename T>
-__global__ void im2col_conv1_kernel(const uint8_t* __restrict__ src_u8, const float* __restrict__ src_f32, T* __restrict__ out,
-                                    int n, int S, int OH) {
-    const size_t total = (size_t)n * OH * OH * (CONV1_KP / 8);
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % (CONV1_KP / 8));
-        const size_t m = idx / (CONV1_KP / 8);
-        const int ow = (int)(m % OH), oh = (int)((m / OH) % OH), img = (int)(m / ((size_t)OH * OH));
+__global__ __launch_bounds__(256) void im2col_conv1_kernel(const uint8_t* __restrict__ src_u8, const float* __restrict__ src_f32,
+                                                           T* __restrict__ out, int n, int S, int OH) {
+    __shared__ float lut[3][256];
+    __shared__ int8_t t_kh[CONV1_KP], t_kw[CONV1_KP], t_c[CONV1_KP];
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) {
+        const int c = i >> 8, v = i & 255;
+        const float p = (float)v / 255.0f;
+        lut[c][v] = (p - BN_MEAN[c]) / BN_STD[c];
+    }
+    for (int k = threadIdx.x; k < CONV1_KP; k += 256) {
+        const int tap = k / 3;
+        t_c[k] = k < CONV1_K ? (int8_t)(k - tap * 3) : (int8_t)-1;
+        t_kh[k] = (int8_t)(tap / 7);
+        t_kw[k] = (int8_t)(tap % 7);
+    }
+    __syncthreads();
+    constexpr int CH = CONV1_KP / 8;     // 19 chunks of 8
+    // 32-bit index arithmetic (64-bit div/mod costs hundreds of instructions per element; total < 2^31 checked by the caller)
+    const uint32_t total = (uint32_t)n * OH * OH * CH;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const uint32_t ch = idx % CH;
+        const uint32_t m = idx / CH;
+        const uint32_t t1 = m / OH;
+        const int ow = (int)(m - t1 * OH), img = (int)(t1 / OH), oh = (int)(t1 - (uint32_t)img * OH);
+        const int ih0 = oh * 2 - 3, iw0 = ow * 2 - 3;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = ch * 8 + e;
+            const int c = t_c[k];
+            const int ih = ih0 + t_kh[k], iw = iw0 + t_kw[k];
             float x = 0.f;
-            if (k < CONV1_K) {
-                const int tap = k / 3, c = k - tap * 3;
-                const int kh = tap / 7, kw = tap - kh * 7;
-                const int ih = oh * 2 - 3 + kh, iw = ow * 2 - 3 + kw;
-                if ((unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) {
-                    if (src_u8) {
-                        // ConvertImageDtype(float): u8 / 255 ; Normalize: (x - mean) / std, all fp32
-                        const float p = (float)src_u8[(((size_t)img * S + ih) * S + iw) * 3 + c] / 255.0f;
-                        x = (p - BN_MEAN[c]) / BN_STD[c];
-                    } else {
-                        x = src_f32[(((size_t)img * 3 + c) * S + ih) * S + iw];
-                    }
-                }
+            if (c >= 0 && (unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) {
+                if (src_u8) x = lut[c][src_u8[(((size_t)img * S + ih) * S + iw) * 3 + c]];
+                else x = src_f32[(((size_t)img * 3 + c) * S + ih) * S + iw];
             }
             v[e] = x;
         }
         if constexpr (sizeof(T) == 2) {
             u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-            *reinterpret_cast<u32x4*>(out + m * CONV1_KP + ch * 8) = o;
+            *reinterpret_cast<u32x4*>(out + (size_t)m * CONV1_KP + ch * 8) = o;
         } else {
             f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-            *reinterpret_cast<f32x4*>(out + m * CONV1_KP + ch * 8) = a;
-            *reinterpret_cast<f32x4*>(out + m * CONV1_KP + ch * 8 + 4) = b;
+            *reinterpret_cast<f32x4*>(out + (size_t)m * CONV1_KP + ch * 8) = a;
+            *reinterpret_cast<f32x4*>(out + (size_t)m * CONV1_KP + ch * 8 + 4) = b;
         }
     }
 }
@@ -68,24 +81,48 @@ __device__ __forceinline__ float ldf(const bf16_t* p) { return bf16_to_f32(*p); 
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
-// MaxPool2d(3, stride 2, padding 1) on NHWC (resnet.py:105); thread = (pixel, channel)
+// MaxPool2d(3, stride 2, padding 1) on NHWC (resnet.py:105); thread = (pixel, 16-byte channel group)
 template <typename T>
-__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int n, int H, int OH, int C) {
-    const size_t total = (size_t)n * OH * OH * C;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C);
-        const size_t px = idx / C;
-        const int ow = (int)(px % OH), oh = (int)((px / OH) % OH), img = (int)(px / ((size_t)OH * OH));
-        float best = -INFINITY;
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int n, int H, int OH, int C) {
+    constexpr int V = 16 / (int)sizeof(T);     // channels per 16-byte access
+    const int CG = C / V;
+    const uint32_t total = (uint32_t)n * OH * OH * CG;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const uint32_t cg = idx % CG;
+        const uint32_t px = idx / CG;
+        const uint32_t t1 = px / OH;
+        const int ow = (int)(px - t1 * OH), img = (int)(t1 / OH), oh = (int)(t1 - (uint32_t)img * OH);
+        float best[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) best[e] = -INFINITY;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)H)
-                    best = fmaxf(best, ldf(in + (((size_t)img * H + ih) * H + iw) * C + c));
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)H) {
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(in + (((size_t)img * H + ih) * H + iw) * C + cg * V);
+                    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            best[2 * e] = fmaxf(best[2 * e], __uint_as_float(t[e] << 16));
+                            best[2 * e + 1] = fmaxf(best[2 * e + 1], __uint_as_float(t[e] & 0xffff0000u));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], __uint_as_float(t[e]));
+                    }
+                }
             }
-        stf(out + idx, best);
+        u32x4 o;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__float_as_uint(best[2 * e]) >> 16) | (__float_as_uint(best[2 * e + 1]) & 0xffff0000u);   // exact: values are bf16
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(best[e]);
+        }
+        *reinterpret_cast<u32x4*>(out + (size_t)px * C + cg * V) = o;
     }
 }
 
@@ -223,7 +260,7 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
     }
     int H = OH1 / 2;    // after the max-pool
     {
-        const size_t work = (size_t)n * H * H * 64;
+        const size_t work = (size_t)n * H * H * 64 / (16 / es);
         size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
         if (lp) hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, st, (const bf16_t*)b.act[0], (bf16_t*)b.act[1], n, OH1, H, 64);
         else hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3((int)nb), dim3(256), 0, st, (const float*)b.act[0], (float*)b.act[1], n, OH1, H, 64);
