@@ -57,6 +57,48 @@ __device__ __forceinline__ int block_reduce_sum_int(int v, int* sh /*[16]*/) {
     return r;
 }
 
+// T values per thread reduced together: 2 barriers for the whole set (the seeding loop is barrier-latency bound)
+template <int T>
+__device__ __forceinline__ void block_reduce_sum_n(double (&v)[T], double* sh /*[16 * T]*/) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int t = 0; t < T; ++t) v[t] = wave_sum_f64(v[t]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) sh[wv * T + t] = v[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        double r = 0.0;
+        for (int i = 0; i < nw; ++i) r += sh[i * T + t];
+        v[t] = r;
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void block_reduce_sum_n_int(int (&v)[T], int* sh /*[16 * T]*/) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[t] += __shfl_xor(v[t], o, 64);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) sh[wv * T + t] = v[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        int r = 0;
+        for (int i = 0; i < nw; ++i) r += sh[i * T + t];
+        v[t] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // 1. centring + tolerance
 // ------------------------------------------------------------------------------------------
@@ -169,13 +211,12 @@ __device__ __forceinline__ float seed_dist(const double* G, int n, int c, int j,
 template <int PTS>   // points per thread (n <= PTS * blockDim.x)
 __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __restrict__ Gall, const double* __restrict__ uniforms,
                                                              int first, int n, int k, int trials, int* __restrict__ seeds) {
-    __shared__ double sh[16];
-    __shared__ int shi[16];
+    __shared__ double sh[16 * KM_MAX_TRIALS];
+    __shared__ int shi[16 * KM_MAX_TRIALS];
     __shared__ double scan_w[16];
-    __shared__ int s_cand[KM_MAX_TRIALS];
     const double* G = Gall + (size_t)blockIdx.x * n * n;
     int* out = seeds + (size_t)blockIdx.x * k;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // thread owns the CONTIGUOUS points [tid*PTS, tid*PTS+PTS) so the scan is a plain blocked scan
     float closest[PTS];
@@ -209,32 +250,45 @@ __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __res
         double woff = 0.0;
         for (int i = 0; i < wv; ++i) woff += scan_w[i];
         const double excl = woff + wscan - run;          // sum of everything before this thread's points
-        // candidates: searchsorted(cumsum, u * pot, side='left') = #{cum < value}, clipped to n-1
-        for (int t = 0; t < trials; ++t) {
-            const double rv = uniforms[(size_t)(c - 1) * trials + t] * (double)pot;
-            int cnt = 0;
+        // candidates: searchsorted(cumsum, u * pot, side='left') = #{cum < value}, clipped to n-1 (all trials at once)
+        int cnt[KM_MAX_TRIALS];
 #pragma unroll
-            for (int q = 0; q < PTS; ++q)
-                if (tid * PTS + q < n && excl + incl[q] < rv) ++cnt;
-            cnt = block_reduce_sum_int(cnt, shi);
-            if (tid == 0) s_cand[t] = cnt > n - 1 ? n - 1 : cnt;
-        }
-        __syncthreads();
-        // potentials of the candidates
-        float best_pot = 0.f;
-        int best_t = 0;
-        for (int t = 0; t < trials; ++t) {
-            const int cand = s_cand[t];
-            double p = 0.0;
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) {
+            cnt[t] = 0;
+            if (t < trials) {
+                const double rv = uniforms[(size_t)(c - 1) * trials + t] * (double)pot;
 #pragma unroll
-            for (int q = 0; q < PTS; ++q) {
-                const int j = tid * PTS + q;
-                if (j < n) p += (double)fminf(closest[q], seed_dist(G, n, cand, j, nrm[q]));
+                for (int q = 0; q < PTS; ++q)
+                    if (tid * PTS + q < n && excl + incl[q] < rv) ++cnt[t];
             }
-            const float pt = (float)block_reduce_sum(p, sh);
-            if (t == 0 || pt < best_pot) { best_pot = pt; best_t = t; }     // np.argmin: first minimum
         }
-        const int chosen = s_cand[best_t];
+        block_reduce_sum_n_int<KM_MAX_TRIALS>(cnt, shi);
+        int cand[KM_MAX_TRIALS];
+#pragma unroll
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) cand[t] = cnt[t] > n - 1 ? n - 1 : cnt[t];
+        // potentials of the candidates (one pass over this thread's points for all trials)
+        double p[KM_MAX_TRIALS];
+#pragma unroll
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) {
+            p[t] = 0.0;
+            if (t < trials) {
+#pragma unroll
+                for (int q = 0; q < PTS; ++q) {
+                    const int j = tid * PTS + q;
+                    if (j < n) p[t] += (double)fminf(closest[q], seed_dist(G, n, cand[t], j, nrm[q]));
+                }
+            }
+        }
+        block_reduce_sum_n<KM_MAX_TRIALS>(p, sh);
+        float best_pot = (float)p[0];
+        int best_t = 0;
+#pragma unroll
+        for (int t = 1; t < KM_MAX_TRIALS; ++t)
+            if (t < trials && (float)p[t] < best_pot) { best_pot = (float)p[t]; best_t = t; }     // np.argmin: first minimum
+        int chosen = cand[0];
+#pragma unroll
+        for (int t = 1; t < KM_MAX_TRIALS; ++t)
+            if (t == best_t) chosen = cand[t];
         pot = best_pot;
 #pragma unroll
         for (int q = 0; q < PTS; ++q) {
@@ -242,7 +296,6 @@ __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __res
             if (j < n) closest[q] = fminf(closest[q], seed_dist(G, n, chosen, j, nrm[q]));
         }
         if (tid == 0) out[c] = chosen;
-        __syncthreads();
     }
 }
 

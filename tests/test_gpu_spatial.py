@@ -1,0 +1,71 @@
+"""sliding_window_method (spatial_vis/visualize.py:35-102) vs a literal CPU loop over the oracle model."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vis_oracle  # noqa: E402  (checker only)
+from sequoia_pub_amd import _lib  # noqa: E402
+from sequoia_pub_amd.spatial import enumerate_windows, sliding_window_method  # noqa: E402
+from sequoia_pub_amd.vis import ViS  # noqa: E402
+
+
+def reference_loop(df, feats, sd, genes, stride, literal_2d):
+    """visualize.py:35-102 restated with the oracle as the model (features come from the cache)."""
+    max_x, max_y = max(df['xcoord_tf']), max(df['ycoord_tf'])
+    preds = {g: {} for g in genes}
+    for x in range(0, max_x, stride):
+        for y in range(0, max_y, stride):
+            window = df[((df['xcoord_tf'] >= x) & (df['xcoord_tf'] < (x + 10))) & ((df['ycoord_tf'] >= y) & (df['ycoord_tf'] < (y + 10)))]
+            if window.shape[0] > 50:
+                fa = feats[window.index.values]
+                if fa.shape[0] < 100:
+                    fa = torch.cat([fa, torch.zeros(100 - fa.shape[0], fa.shape[1])])
+                with torch.no_grad():
+                    out = vis_oracle.vis_forward(sd, fa[:, None, :] if literal_2d else fa[None])[0].numpy()
+                for g in genes:
+                    for key in window.index:
+                        if stride == 10:
+                            preds[g][key] = out[g]
+                        else:
+                            preds[g].setdefault(key, []).append(out[g])
+    if stride < 10:
+        for g in genes:
+            for key in preds[g]:
+                preds[g][key] = np.mean(preds[g][key])
+    return preds
+
+
+@pytest.mark.parametrize("stride,literal", [(10, False), (3, False), (1, False), (5, True)])
+def test_sliding_window_matches_literal_loop(stride, literal):
+    _lib.require_gpu()
+    rs = np.random.RandomState(0)
+    coords = [(x, y) for x in range(24) for y in range(19) if rs.rand() > 0.25]      # holes in the tissue mask
+    df = pd.DataFrame(coords, columns=["xcoord_tf", "ycoord_tf"])
+    feats = torch.from_numpy(rs.randn(len(df), 128).astype(np.float32))
+    cfg = dict(num_outputs=40, input_dim=128, depth=1, nheads=2, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=5), seed=6)
+    m = ViS(**cfg, device="cuda:0")
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    genes = [0, 7, 39]
+    got = sliding_window_method(df, feats, m, genes, stride, literal_2d=literal, batch_windows=37)
+    ref = reference_loop(df, feats, sd, genes, stride, literal)
+    for g in genes:
+        assert set(got[g].keys()) == set(ref[g].keys()) and len(ref[g]) > 100
+        a = np.array([got[g][k] for k in sorted(ref[g])])
+        b = np.array([ref[g][k] for k in sorted(ref[g])])
+        assert rel_err(a, b) < 1e-4
+
+
+def test_window_enumeration_rules():
+    xs, ys = np.meshgrid(np.arange(12), np.arange(9), indexing="ij")
+    members, origins = enumerate_windows(xs.ravel(), ys.ravel(), stride=1)
+    # window at (0,0) holds 10*9 = 90 tiles (y only reaches 8), ascending df positions, -1 padded
+    assert (members[0] >= 0).sum() == 90 and np.all(np.diff(members[0][:90]) > 0) and np.all(members[0][90:] == -1)
+    assert all(((members[i] >= 0).sum() > 50) for i in range(len(members)))
+    assert origins[:, 0].max() < 11 and origins[:, 1].max() < 8          # range(0, max, stride) excludes the max itself
