@@ -98,6 +98,36 @@ int sq_vis_backward(const sq_vis_config* cfg, int dtype, const float* params, co
                     size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, sq_stream_t stream);
 
 /* ------------------------------------------------------------------------------
+ * Softmax ViT baseline  (src/vit.py:49-115: Attention :49-74, Transformer :76-89, ViT :91-115;
+ * `--model_type vit`, src/main.py:160-163: mlp_dim 2048, dim_head 64).  Same conventions as ViS:
+ * one flat fp32 parameter buffer (sq_vit_layout), optional bf16 shadow, workspace from *_workspace_bytes.
+ * ---------------------------------------------------------------------------- */
+typedef struct sq_vit_config {
+    int32_t dim, depth, heads, mlp_dim, num_outputs, num_clusters; /* dim_head = 64 */
+} sq_vit_config;
+typedef struct sq_vit_layer_offsets {
+    int64_t ln1_g, ln1_b; /* layers.{l}.0.norm                         */
+    int64_t qkv_w;        /* layers.{l}.0.to_qkv.weight [3*heads*64][dim] */
+    int64_t out_w;        /* layers.{l}.0.to_out.weight [dim][heads*64]   */
+    int64_t ln2_g, ln2_b; /* layers.{l}.1.net.0                         */
+    int64_t ff1_w, ff1_b; /* layers.{l}.1.net.1 Linear(dim, mlp_dim)    */
+    int64_t ff2_w, ff2_b; /* layers.{l}.1.net.3 Linear(mlp_dim, dim)    */
+} sq_vit_layer_offsets;
+typedef struct sq_vit_layout {
+    int64_t pos, head_ln_g, head_ln_b, head_w, head_b, total;
+    sq_vit_layer_offsets layer[SQ_MAX_DEPTH];
+} sq_vit_layout;
+int sq_vit_layout_init(const sq_vit_config* cfg, sq_vit_layout* out);
+size_t sq_vit_workspace_bytes(const sq_vit_config* cfg, int dtype, int batch, int save_for_backward);
+int sq_vit_forward(const sq_vit_config* cfg, int dtype, const float* params, const void* params_lp, const float* x,
+                   float* out, int batch, int save_for_backward, void* workspace, size_t workspace_bytes,
+                   sq_stream_t stream);
+size_t sq_vit_backward_workspace_bytes(const sq_vit_config* cfg, int dtype, int batch);
+int sq_vit_backward(const sq_vit_config* cfg, int dtype, const float* params, const void* params_lp,
+                    const float* grad_out, float* grad_params, float* grad_x, int batch, void* fwd_workspace,
+                    size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, sq_stream_t stream);
+
+/* ------------------------------------------------------------------------------
  * Training-step pieces of src/vit.py:117-243 `train`
  * ---------------------------------------------------------------------------- */
 size_t sq_train_scratch_bytes(int num_outputs);

@@ -40,6 +40,23 @@ class VisLayout(ctypes.Structure):
                 ("layer", VisLayerOffsets * SQ_MAX_DEPTH)]
 
 
+class VitConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("dim", "depth", "heads", "mlp_dim", "num_outputs", "num_clusters")]
+
+
+_VIT_LAYER_FIELDS = ["ln1_g", "ln1_b", "qkv_w", "out_w", "ln2_g", "ln2_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b"]
+
+
+class VitLayerOffsets(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in _VIT_LAYER_FIELDS]
+
+
+class VitLayout(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_int64), ("head_ln_g", ctypes.c_int64), ("head_ln_b", ctypes.c_int64),
+                ("head_w", ctypes.c_int64), ("head_b", ctypes.c_int64), ("total", ctypes.c_int64),
+                ("layer", VitLayerOffsets * SQ_MAX_DEPTH)]
+
+
 class ConvDesc(ctypes.Structure):
     _fields_ = [("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32),
                 ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("k_padded", ctypes.c_int32)]
@@ -91,6 +108,16 @@ def _declare(lib):
     lib.sq_resnet50_workspace_bytes.argtypes = [i32, i32, i32]
     lib.sq_resnet50_extract.restype = i32
     lib.sq_resnet50_extract.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    lib.sq_vit_layout_init.restype = i32
+    lib.sq_vit_layout_init.argtypes = [ctypes.POINTER(VitConfig), ctypes.POINTER(VitLayout)]
+    lib.sq_vit_workspace_bytes.restype = sz
+    lib.sq_vit_workspace_bytes.argtypes = [ctypes.POINTER(VitConfig), i32, i32, i32]
+    lib.sq_vit_forward.restype = i32
+    lib.sq_vit_forward.argtypes = [ctypes.POINTER(VitConfig), i32, vp, vp, vp, vp, i32, i32, vp, sz, vp]
+    lib.sq_vit_backward_workspace_bytes.restype = sz
+    lib.sq_vit_backward_workspace_bytes.argtypes = [ctypes.POINTER(VitConfig), i32, i32]
+    lib.sq_vit_backward.restype = i32
+    lib.sq_vit_backward.argtypes = [ctypes.POINTER(VitConfig), i32, vp, vp, vp, vp, vp, i32, vp, sz, vp, sz, vp]
     lib.sq_prof_enable.restype = i32
     lib.sq_prof_enable.argtypes = [i32]
     lib.sq_prof_report.restype = i32

@@ -19,8 +19,12 @@ from .common import init_distributed, seed_everything
 
 
 def build_model(args, num_outputs, feature_dim, device):
+    if args.model_type == 'vit':                       # src/main.py:141-143,160-163
+        from ..vit import ViT
+        return ViT(num_outputs=num_outputs, dim=feature_dim, depth=args.depth, heads=args.num_heads, mlp_dim=2048,
+                   dim_head=64, device=str(device), compute_dtype=args.compute_dtype)
     if args.model_type != 'vis':
-        raise SystemExit('--model_type vit (softmax ViT baseline, src/vit.py:49-115) is not built yet; use --model_type vis')
+        raise SystemExit('please specify correct model type "vit" or "vis"')
     return ViS(num_outputs=num_outputs, input_dim=feature_dim, depth=args.depth, nheads=args.num_heads,
                dimensions_f=64, dimensions_c=64, dimensions_s=64, device=str(device), compute_dtype=args.compute_dtype)
 

@@ -35,16 +35,16 @@ def vis_backward(model, grad_out, batch, need_x_grad):
     """sq_vis_backward on the workspace the matching forward saved.  Returns (grad_flat, grad_x)."""
     dev = model.flat.device
     grad_out = grad_out.to(dev, torch.float32).contiguous()
-    need = _lib.lib().sq_vis_backward_workspace_bytes(ctypes.byref(model.cfg), model.compute_dtype, batch)
+    need = getattr(_lib.lib(), model._C_BWS)(ctypes.byref(model.cfg), model.compute_dtype, batch)
     if getattr(model, "_bws", None) is None or model._bws.numel() < need or model._bws.device != dev:
         model._bws = torch.empty(need, dtype=torch.uint8, device=dev)
     gflat = getattr(model, "_gflat", None)
     if gflat is None or gflat.shape != model.flat.shape or gflat.device != dev:
         gflat = model._gflat = torch.zeros_like(model.flat.detach())
-    gx = torch.empty(batch, model.cfg.num_clusters, model.cfg.input_dim, device=dev) if need_x_grad else None
+    gx = torch.empty(batch, model.cfg.num_clusters, model._dim(), device=dev) if need_x_grad else None
     ws = model._ws
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().sq_vis_backward(
+        _lib.check(getattr(_lib.lib(), model._C_BWD)(
             ctypes.byref(model.cfg), model.compute_dtype, _lib.ptr(model.flat), _lib.ptr(model._params_lp()),
             _lib.ptr(grad_out), _lib.ptr(gflat), _lib.ptr(gx), batch, _lib.ptr(ws), ws.numel(),
             _lib.ptr(model._bws), model._bws.numel(), _lib.stream_ptr(dev)))

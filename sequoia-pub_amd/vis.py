@@ -102,6 +102,12 @@ class _VisFunction(torch.autograd.Function):
 
 
 class ViS(nn.Module, PyTorchModelHubMixin):
+    # C entry points and config accessors (the ViT baseline subclasses this plumbing, vit.py)
+    _C_WS, _C_FWD, _C_BWS, _C_BWD = "sq_vis_workspace_bytes", "sq_vis_forward", "sq_vis_backward_workspace_bytes", "sq_vis_backward"
+
+    def _dim(self):
+        return self.cfg.input_dim
+
     """Drop-in for the reference ``ViS`` (tformer_lin.py:80-106); see module docstring.
 
     Extra keyword ``compute_dtype``: ``"fp32"`` (exact-fp32 MFMA, parity mode, default) or
@@ -248,7 +254,7 @@ class ViS(nn.Module, PyTorchModelHubMixin):
 
     def _workspace(self, batch, save):
         key = (batch, bool(save), self.compute_dtype, self.flat.device)
-        need = _lib.lib().sq_vis_workspace_bytes(ctypes.byref(self.cfg), self.compute_dtype, batch, int(save))
+        need = getattr(_lib.lib(), self._C_WS)(ctypes.byref(self.cfg), self.compute_dtype, batch, int(save))
         if need == 0:
             _lib.check(-1)
         if self._ws is None or self._ws_key != key or self._ws.numel() < need:
@@ -263,15 +269,15 @@ class ViS(nn.Module, PyTorchModelHubMixin):
         x = x.detach().to(self.flat.device, torch.float32)
         x = x.reshape(x.shape[0], -1, x.shape[-1]).contiguous()      # rearrange 'b ... d -> b (...) d'
         B, N, D = x.shape
-        if N != self.cfg.num_clusters or D != self.cfg.input_dim:
-            raise ValueError(f"expected [B, {self.cfg.num_clusters}, {self.cfg.input_dim}] tokens, got {tuple(x.shape)}")
+        if N != self.cfg.num_clusters or D != self._dim():
+            raise ValueError(f"expected [B, {self.cfg.num_clusters}, {self._dim()}] tokens, got {tuple(x.shape)}")
         out = torch.empty(B, self.cfg.num_outputs, dtype=torch.float32, device=x.device)
         ws = self._workspace(B, save)
         lp = self._params_lp()
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().sq_vis_forward(ctypes.byref(self.cfg), self.compute_dtype, _lib.ptr(self.flat),
-                                                 _lib.ptr(lp), _lib.ptr(x), _lib.ptr(out), B, int(save),
-                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
+            _lib.check(getattr(_lib.lib(), self._C_FWD)(ctypes.byref(self.cfg), self.compute_dtype, _lib.ptr(self.flat),
+                                                         _lib.ptr(lp), _lib.ptr(x), _lib.ptr(out), B, int(save),
+                                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
         self._saved_x = x if save else None
         return out
 

@@ -96,6 +96,31 @@ def gold_vis_tiny():
     print("vis_tiny: loss", float(loss), "losses3", losses)
 
 
+def gold_vit_tiny():
+    """Softmax ViT baseline (src/vit.py:91-115) at dims the HIP kernels run: weights stored in full."""
+    cfg = dict(num_outputs=40, dim=128, depth=2, heads=2, mlp_dim=256)
+    torch.manual_seed(17)
+    model = ref_vit.ViT(**cfg, dim_head=64, num_clusters=100, device="cpu")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(19)
+    for k in sd:                                               # non-trivial LayerNorm parameters
+        if k.endswith("norm.weight") or k.endswith("net.0.weight") or k == "linear_head.0.weight":
+            sd[k] = 1.0 + 0.2 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith("norm.bias") or k.endswith("net.0.bias") or k == "linear_head.0.bias":
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    model.load_state_dict(sd)
+    x = torch.randn(3, 100, 128, generator=g)
+    target = torch.rand(3, 40, generator=g) * 8
+    pred = model(x)
+    loss = torch.nn.MSELoss()(pred, target)
+    loss.backward()
+    out = {"w::" + k: v for k, v in np_sd(sd).items()}
+    out.update({"g::" + k: p.grad.detach().numpy().copy() for k, p in model.named_parameters()})
+    out.update(x=x.numpy(), target=target.numpy(), pred=pred.detach().numpy(), loss=np.array(float(loss)))
+    np.savez_compressed(os.path.join(HERE, "vit_tiny.npz"), **out)
+    print("vit_tiny: loss", float(loss))
+
+
 def gold_vis_full():
     """Full-size ViS (D=1024, 6 layers, 16 heads, G=20820): weights by seed recipe."""
     cfg = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16, dimensions_f=64,
@@ -229,7 +254,9 @@ def gold_metrics_and_train():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vis_tiny", "vis_full", "resnet", "kmeans", "metrics"]
+    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics"]
+    if "vit_tiny" in which:
+        gold_vit_tiny()
     if "vis_tiny" in which:
         gold_vis_tiny()
     if "vis_full" in which:

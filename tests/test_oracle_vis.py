@@ -80,3 +80,15 @@ def test_config_recovery(golden_dir):
     cfg = vis_oracle.vis_config_from_state_dict(_sd(z, "w::"))
     assert cfg == dict(input_dim=128, depth=2, nheads=2, dimensions_f=64, dimensions_s=64,
                        dimensions_c=64, num_outputs=50, num_clusters=100)
+
+
+def test_vit_tiny_matches_reference(golden_dir):
+    """src/vit.py:49-115 softmax ViT baseline: oracle forward + grads vs the reference module's."""
+    z = _load(golden_dir, "vit_tiny.npz")
+    sd = _sd(z, "w::")
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["target"])
+    np.testing.assert_allclose(vis_oracle.vit_forward(sd, x, heads=2).numpy(), z["pred"], rtol=1e-6, atol=1e-6)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.nn.functional.mse_loss(vis_oracle.vit_forward(leaf, x, heads=2), t).backward()
+    for k, g in _sd(z, "g::").items():
+        np.testing.assert_allclose(leaf[k].grad.numpy(), g.numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
