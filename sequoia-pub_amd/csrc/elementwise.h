@@ -18,6 +18,20 @@ int sq_k_bf16_to_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s);
 // batched with element strides.  The zero padding lets ragged R feed the GEMM's 16-byte K chunks.
 int sq_k_transpose(const void* src, int lds_, void* dst, int ldd, int R, int C, int elem_size, int batch,
                    long long sstride, long long dstride, hipStream_t s);
+// the same, many matrices in ONE launch (a backward pass transposes every weight once)
+#define SQ_MAX_TRANSPOSE_JOBS 64
+struct sq_transpose_job {
+    const void* src; void* dst;
+    long long sstride, dstride;        // element strides between the matrices of a batched job
+    int lds, ldd, R, C, tile0;
+};
+struct sq_transpose_jobs {
+    sq_transpose_job job[SQ_MAX_TRANSPOSE_JOBS];
+    int n = 0, tiles = 0;
+};
+int sq_transpose_jobs_add(sq_transpose_jobs* jobs, const void* src, int lds_, void* dst, int ldd, int R, int C, int batch,
+                          long long sstride, long long dstride);
+int sq_k_transpose_multi(const sq_transpose_jobs& jobs, int elem_size, hipStream_t s);
 // dst[r][0:C] = (T) src[r][0:C], dst[r][C:ldd] = 0
 int sq_k_cast_pad(const float* src, int lds_, void* dst, int dst_dtype, int ldd, int R, int C, hipStream_t s);
 

@@ -163,6 +163,33 @@ __global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ sr
     }
 }
 
+// many transposes in one launch: block -> job by tile prefix; same 64x64 LDS tile as transpose_kernel
+template <typename E>
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const sq_transpose_jobs jobs) {
+    __shared__ E tile[64][65];
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].tile0) ++j;
+    const sq_transpose_job& J = jobs.job[j];
+    int t = blockIdx.x - J.tile0;
+    const int tc = (J.C + 63) / 64, tr = (J.ldd + 63) / 64;
+    const int z = t / (tc * tr);
+    t -= z * tc * tr;
+    const E* src = reinterpret_cast<const E*>(J.src) + (long long)z * J.sstride;
+    E* dst = reinterpret_cast<E*>(J.dst) + (long long)z * J.dstride;
+    const int c0 = (t % tc) * 64, r0 = (t / tc) * 64;
+    const int R = J.R, C = J.C, ldd = J.ldd, lds_ = J.lds;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(size_t)r * lds_ + c] : (E)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < ldd && c < C) dst[(size_t)c * ldd + r] = tile[tx][i];
+    }
+}
+
 __global__ void cast_pad_kernel(const float* __restrict__ src, int lds_, void* __restrict__ dst, int out_bf16, int ldd, int R, int C) {
     const uint32_t total = (uint32_t)R * ldd;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -247,6 +274,26 @@ int sq_k_transpose(const void* src, int lds_, void* dst, int ldd, int R, int C, 
     else if (elem_size == 4)
         hipLaunchKernelGGL(transpose_kernel<uint32_t>, grid, block, 0, s, (const uint32_t*)src, lds_, (uint32_t*)dst, ldd, R, C, sstride, dstride);
     else { sq_set_error("transpose: elem_size %d", elem_size); return SQ_ERR_ARG; }
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_transpose_jobs_add(sq_transpose_jobs* jobs, const void* src, int lds_, void* dst, int ldd, int R, int C, int batch,
+                          long long sstride, long long dstride) {
+    SQ_REQUIRE(jobs->n < SQ_MAX_TRANSPOSE_JOBS, "transpose_multi: more than %d jobs", SQ_MAX_TRANSPOSE_JOBS);
+    SQ_REQUIRE(ldd >= R && lds_ >= C && batch >= 1, "transpose_multi: ldd=%d < R=%d or lds=%d < C=%d", ldd, R, lds_, C);
+    sq_transpose_job& J = jobs->job[jobs->n++];
+    J.src = src; J.dst = dst; J.lds = lds_; J.ldd = ldd; J.R = R; J.C = C; J.sstride = sstride; J.dstride = dstride;
+    J.tile0 = jobs->tiles;
+    jobs->tiles += ((C + 63) / 64) * ((ldd + 63) / 64) * batch;
+    return SQ_OK;
+}
+
+int sq_k_transpose_multi(const sq_transpose_jobs& jobs, int elem_size, hipStream_t s) {
+    if (jobs.n == 0) return SQ_OK;
+    if (elem_size == 2) hipLaunchKernelGGL(transpose_multi_kernel<uint16_t>, dim3(jobs.tiles), dim3(256), 0, s, jobs);
+    else if (elem_size == 4) hipLaunchKernelGGL(transpose_multi_kernel<uint32_t>, dim3(jobs.tiles), dim3(256), 0, s, jobs);
+    else { sq_set_error("transpose_multi: elem_size %d", elem_size); return SQ_ERR_ARG; }
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }

@@ -199,27 +199,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 
     const int l31 = lane & 31, lh = lane >> 5;
 
+    // fragment addresses inside a tile are loop-invariant: row * 128 + ((chunk ^ swz(row)) << 4)
+    int fa_off[WTM][4], fb_off[WTN][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int chunk = 2 * s + lh;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) {
+            const int row = wm * (WTM * 32) + i * 32 + l31;
+            fa_off[i][s] = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+            const int row = wn * (WTN * 32) + j * 32 + l31;
+            fb_off[j][s] = BM * 128 + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        }
+    }
+
+    // k-step s+1's fragments are fetched from LDS while the MFMAs of k-step s run (two register sets)
     auto compute = [&](int buf) {
-        const char* sa = smem + buf * TILE_BYTES;
-        const char* sb = sa + BM * 128;
+        const char* st = smem + buf * TILE_BYTES;
+        u32x4 fa[2][WTM], fb[2][WTN];
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) fa[0][i] = lds_read128(st + fa_off[i][0]);
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) fb[0][j] = lds_read128(st + fb_off[j][0]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int chunk = 2 * s + lh;
-            u32x4 fa[WTM], fb[WTN];
+            if (s < 3) {
 #pragma unroll
-            for (int i = 0; i < WTM; ++i) {
-                const int row = wm * (WTM * 32) + i * 32 + l31;
-                fa[i] = lds_read128(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-            }
+                for (int i = 0; i < WTM; ++i) fa[(s + 1) & 1][i] = lds_read128(st + fa_off[i][s + 1]);
 #pragma unroll
-            for (int j = 0; j < WTN; ++j) {
-                const int row = wn * (WTN * 32) + j * 32 + l31;
-                fb[j] = lds_read128(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                for (int j = 0; j < WTN; ++j) fb[(s + 1) & 1][j] = lds_read128(st + fb_off[j][s + 1]);
             }
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of this k-step's MFMAs
 #pragma unroll
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < WTN; ++j) Mma<T>::run(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
         }
     };
 

@@ -5,8 +5,9 @@
 // as they are (rows of 128 outputs = 256 B bf16 / 512 B fp32, fully coalesced) and the MFMA fragments are
 // read "down the columns":
 //   bf16: v_mfma_f32_16x16x32_bf16 -- lane (i = l&15, g = l>>4) needs k = 8g..8g+7 of column i:
-//         eight ds_read_u16 per fragment, 16-B chunks XOR-swizzled by 2*((row>>3)&3) on the DMA source
-//         so the four lane groups of one read hit disjoint banks
+//         two ds_read_b64_tr_b16 (gfx950's transposing LDS read, 4 rows x 16 columns per 16-lane group)
+//         per fragment; 16-B chunks XOR-swizzled on the DMA source by 2*((row&3) | ((row>>3)&1)<<2) so the
+//         eight 32-byte row pieces one half-wave reads fall in eight different bank slots
 //   fp32: v_mfma_f32_16x16x4_f32   -- lane (i, g) needs row g of column i: one conflict-free ds_read_b32
 //         (chunks swizzled by (row&3)<<2)
 // Block = 128 x 128 outputs, 4 waves (2x2) x 4x4 MFMA tiles, contraction walked 64 (bf16) / 32 (fp32) rows
@@ -23,6 +24,18 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, uint32_t voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_base, 16, voffset, soffset, 0, 0);
+}
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 lds_bf16x4;
+
+// ds_read_b64_tr_b16: within each 16-lane group, lane L supplies the address of 4 contiguous bf16 and lane i
+// receives element (i & 3) of the words supplied by lanes 4j + (i >> 2), j = 0..3 -- a 4 x 16 transpose
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+    const auto v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) lds_bf16x4*)p);
+    bf16x4 r;
+    r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3];
+    return r;
 }
 
 template <typename T>
@@ -51,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
 
     // DMA lane mapping: instruction j of wave w fills rows (j*4 + w) * ROWS_PER_INSTR + lane / CHUNKS
     const int lrow = lane / CHUNKS, lchunk = lane % CHUNKS;
-    auto key = [](int row) { return LP ? (((row >> 3) & 3) << 1) : ((row & 3) << 2); };
+    auto key = [](int row) { return LP ? (((row & 3) | (((row >> 3) & 1) << 2)) << 1) : ((row & 3) << 2); };
 
     const int nk_all = (p.K + KR - 1) / KR;
     const int per = (nk_all + p.splitk - 1) / p.splitk;
@@ -81,6 +94,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int li = lane & 15, lg = lane >> 4;
+    // bf16 transpose-read addressing: lane (g = lane>>4, j = (lane>>2)&3, c = lane&3) hands the hardware the 8 bytes
+    // at row 8g + j, columns 4c..4c+3 of a 16-column block; it receives column lane&15 of the group's four rows
+    int tr_a[4], tr_b[4];
+    {
+        const int j = (lane >> 2) & 3, c = lane & 3;
+        const int row = 8 * lg + j, kx = key(row);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int qa = wm * 8 + 2 * t + (c >> 1), qb = wn * 8 + 2 * t + (c >> 1);     // 16-byte chunk of the column
+            tr_a[t] = row * ROWB + ((qa ^ kx) << 4) + ((c & 1) << 3);
+            tr_b[t] = row * ROWB + ((qb ^ kx) << 4) + ((c & 1) << 3);
+        }
+    }
 
     auto compute = [&](int buf) {
         const char* sa = smem + buf * (2 * TILE_BYTES);
@@ -91,16 +117,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
                 bf16x8 fa[4], fb[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int ca = wm * 64 + t * 16 + li, cb = wn * 64 + t * 16 + li;     // column inside the tile
-                    union { bf16x8 h; uint16_t u[8]; } ua, ub;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int row = 32 * s + 8 * lg + j;
-                        const int kx = ((row >> 3) & 3) << 1;   // = 2 * lg
-                        ua.u[j] = *reinterpret_cast<const uint16_t*>(sa + row * ROWB + (((ca >> 3) ^ kx) << 4) + ((ca & 7) << 1));
-                        ub.u[j] = *reinterpret_cast<const uint16_t*>(sb + row * ROWB + (((cb >> 3) ^ kx) << 4) + ((cb & 7) << 1));
-                    }
-                    fa[t] = ua.h; fb[t] = ub.h;
+                    // rows 32s + 8g + 4h + j of column block t: h = 0 / 1 are the low / high half of the fragment
+                    const bf16x4 a0 = tr_read(sa + s * 32 * ROWB + tr_a[t]), a1 = tr_read(sa + (s * 32 + 4) * ROWB + tr_a[t]);
+                    const bf16x4 b0 = tr_read(sb + s * 32 * ROWB + tr_b[t]), b1 = tr_read(sb + (s * 32 + 4) * ROWB + tr_b[t]);
+                    fa[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    fb[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)

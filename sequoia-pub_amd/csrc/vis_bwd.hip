@@ -19,11 +19,10 @@ struct BwdBufs {
     void* dP;                        // [M, HD] T
     float* dLf;                      // [M, HD] f32
     void* dF;                        // [M, HD] T
-    void* wT;                        // [max(D,HD) * max(D,HD)] T transposed weight
-    void* wcT;                       // [H, 64, 64] T
+    void* whT;                       // [D, Gp] T   transposed weights, all produced by one launch up front
+    struct LayerT { void *ff2, *ff1, *proj, *wc_lf, *wc_ts, *s, *f; } wt[SQ_MAX_DEPTH];
     float* dCs; void* dCs_lp; float* dTs; void* dSm; float* dXbar;   // [B, HD] / [B, D]
     void* dout_lp;                   // [B, Gp] T
-    void* whT;                       // [D, Gp] T
     float* dxn; float* dxm;          // [B, D]
     float* red_ws;                   // reduction scratch
     float* skws; size_t skws_bytes;  // split-K scratch (dW products have K = tokens and few output tiles)
@@ -44,14 +43,18 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
     o->dP = a.take(M * HD * es);
     o->dLf = (float*)a.take(M * HD * 4);
     o->dF = a.take(M * HD * es);
-    o->wT = a.take(W * W * es);
-    o->wcT = a.take((size_t)c.nheads * 64 * 64 * es);
+    o->whT = a.take(D * Gp * es);
+    for (int l = 0; l < c.depth; ++l) {
+        o->wt[l].ff2 = a.take(D * D * es); o->wt[l].ff1 = a.take(D * D * es);
+        o->wt[l].proj = a.take(HD * D * es);
+        o->wt[l].wc_lf = a.take((size_t)c.nheads * 64 * 64 * es); o->wt[l].wc_ts = a.take((size_t)c.nheads * 64 * 64 * es);
+        o->wt[l].s = a.take(D * HD * es); o->wt[l].f = a.take(D * HD * es);
+    }
     o->dCs = (float*)a.take((size_t)B * HD * 4); o->dCs_lp = lp ? a.take((size_t)B * HD * 2) : (void*)o->dCs;
     o->dTs = (float*)a.take((size_t)B * HD * 4);
     o->dSm = a.take((size_t)B * HD * es);
     o->dXbar = (float*)a.take((size_t)B * D * 4);
     o->dout_lp = a.take((size_t)B * Gp * es);
-    o->whT = a.take(D * Gp * es);
     o->dxn = (float*)a.take((size_t)B * D * 4); o->dxm = (float*)a.take((size_t)B * D * 4);
     size_t red = sq_ln_bwd_ws_floats((int)W);
     const size_t cs = sq_colsum_ws_floats((int)(G > W ? G : W));
@@ -119,16 +122,36 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         g.splitk_ws = b.skws; g.splitk_ws_bytes = b.skws_bytes;
         return g;
     };
-    auto tr = [&](const void* src, int lds_, void* dst, int ldd, int R, int C) {
-        return sq_k_transpose(src, lds_, dst, ldd, R, C, es, 1, 0, 0, st);
-    };
 #define RUN(expr) do { if (int _e = (expr)) return _e; } while (0)
+    {   // every "dX = dY . W" below is an NT product on W^T: transpose all weights with one launch
+        sq_transpose_jobs jobs;
+        auto add = [&](const void* src, int lds_, void* dst, int ldd, int R, int C, int batch, long long ss, long long ds) {
+            if (jobs.n == SQ_MAX_TRANSPOSE_JOBS) {               // deeper models than one argument block holds
+                if (int e = sq_k_transpose_multi(jobs, es, st)) return e;
+                jobs = sq_transpose_jobs();
+            }
+            return sq_transpose_jobs_add(&jobs, src, lds_, dst, ldd, R, C, batch, ss, ds);
+        };
+        const long long wcs = (long long)SQ_HEAD_DIM * 2 * SQ_HEAD_DIM, wcd = (long long)SQ_HEAD_DIM * SQ_HEAD_DIM;
+        RUN(add(W(lay.head_w), D, b.whT, Gp, G, D, 1, 0, 0));
+        for (int l = 0; l < c->depth; ++l) {
+            const sq_vis_layer_offsets& L = lay.layer[l];
+            RUN(add(W(L.ff2_w), D, b.wt[l].ff2, D, D, D, 1, 0, 0));
+            RUN(add(W(L.ff1_w), D, b.wt[l].ff1, D, D, D, 1, 0, 0));
+            RUN(add(W(L.proj_w), HD, b.wt[l].proj, D, D, HD, 1, 0, 0));          // Wp [D, HD] -> [HD, D]
+            RUN(add(W(L.c_w), 2 * SQ_HEAD_DIM, b.wt[l].wc_lf, SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, H, wcs, wcd));
+            RUN(add((const char*)W(L.c_w) + (size_t)SQ_HEAD_DIM * es, 2 * SQ_HEAD_DIM, b.wt[l].wc_ts,
+                                      SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, H, wcs, wcd));
+            RUN(add(W(L.s_w), D, b.wt[l].s, HD, HD, D, 1, 0, 0));               // Ws [HD, D] -> [D, HD]
+            RUN(add(W(L.f_w), D, b.wt[l].f, HD, HD, D, 1, 0, 0));               // Wf [HD, D] -> [D, HD]
+        }
+        RUN(sq_k_transpose_multi(jobs, es, st));
+    }
 
     // ---------------- head: out = LN(mean_n X) Wh^T + bh ----------------
     RUN(sq_k_cast_pad(grad_out, G, b.dout_lp, dtype, Gp, B, G, st));
     { GemmArgs g = gemm_tn(b.dout_lp, Gp, w.xn, D, Gp_(lay.head_w), D, G, D, B); RUN(sq_launch_gemm_tn(g, dtype, st)); }
     RUN(sq_k_colsum(grad_out, SQ_F32, B, G, G, b.red_ws, Gp_(lay.head_b), st));
-    RUN(tr(W(lay.head_w), D, b.whT, Gp, G, D));
     { GemmArgs g = gemm(b.dout_lp, Gp, b.whT, Gp, b.dxn, D, B, D, Gp); RUN(sq_launch_gemm(g, dtype, st)); }
     RUN(sq_k_ln_rows_bwd(b.dxn, w.xm, Pf(lay.head_ln_g), nullptr, b.dxm, nullptr, Gp_(lay.head_ln_g), Gp_(lay.head_ln_b),
                          b.red_ws, B, D, st));
@@ -142,16 +165,14 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         // ---------------- FeedForward: X2 = GELU(LN(X1) W1^T + b1) W2^T + b2 + X1 ----------------
         { GemmArgs g = gemm_tn(dXcur_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         RUN(sq_k_colsum(dXcur, SQ_F32, M, D, D, b.red_ws, Gp_(L.ff2_b), st));
-        RUN(tr(W(L.ff2_w), D, b.wT, D, D, D));
         {   // dU = (dX2 . W2) * GELU'(U)
-            GemmArgs g = gemm(dXcur_lp, D, b.wT, D, nullptr, D, M, D, D);
+            GemmArgs g = gemm(dXcur_lp, D, b.wt[l].ff2, D, nullptr, D, M, D, D);
             g.C = b.dU; g.out_dtype = dtype; g.gelu_grad_of = w.U[l]; g.ldgg = D;
             RUN(sq_launch_gemm(g, dtype, st));
         }
         { GemmArgs g = gemm_tn(b.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         RUN(sq_k_colsum(b.dU, dtype, M, D, D, b.red_ws, Gp_(L.ff1_b), st));
-        RUN(tr(W(L.ff1_w), D, b.wT, D, D, D));
-        { GemmArgs g = gemm(b.dU, D, b.wT, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
+        { GemmArgs g = gemm(b.dU, D, b.wt[l].ff1, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
         // dX1 = dX2 + dLN(dY)
         RUN(sq_k_ln_rows_bwd(b.dY, w.X1[l], Pf(L.ffln_g), dXcur, dXoth, lp ? (bf16_t*)dXoth_lp : nullptr, Gp_(L.ffln_g),
                              Gp_(L.ffln_b), b.red_ws, M, D, st));
@@ -160,19 +181,16 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         // ---------------- projection: X1 = O Wp^T + bp + X ----------------
         { GemmArgs g = gemm_tn(dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         RUN(sq_k_colsum(dX1, SQ_F32, M, D, D, b.red_ws, Gp_(L.proj_b), st));
-        RUN(tr(W(L.proj_w), HD, b.wT, D, D, HD));                 // Wp [D, HD] -> [HD, D]
         {   // dP = (dX1 . Wp) * GELU'(P)
-            GemmArgs g = gemm(dX1_lp, D, b.wT, D, nullptr, HD, M, HD, D);
+            GemmArgs g = gemm(dX1_lp, D, b.wt[l].proj, D, nullptr, HD, M, HD, D);
             g.C = b.dP; g.out_dtype = dtype; g.gelu_grad_of = w.P[l]; g.ldgg = HD;
             RUN(sq_launch_gemm(g, dtype, st));
         }
         // ---------------- combiner: P_h = Lf_h Wc_h[:, :64]^T + Ts_h Wc_h[:, 64:]^T + bc_h ----------------
         RUN(sq_k_group_sum(b.dP, dtype, B, N, HD, 1.0f, b.dCs, st));       // dCs[b] = sum_n dP[b, n]
         RUN(sq_k_colsum(b.dCs, SQ_F32, B, HD, HD, b.red_ws, Gp_(L.c_b), st));
-        RUN(sq_k_transpose(W(L.c_w), 2 * SQ_HEAD_DIM, b.wcT, SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, es, H,
-                           SQ_HEAD_DIM * 2 * SQ_HEAD_DIM, SQ_HEAD_DIM * SQ_HEAD_DIM, st));
         {   // dLf_h = dP_h . Wc_h[:, :64]
-            GemmArgs g = gemm(b.dP, HD, b.wcT, SQ_HEAD_DIM, b.dLf, HD, M, SQ_HEAD_DIM, SQ_HEAD_DIM);
+            GemmArgs g = gemm(b.dP, HD, b.wt[l].wc_lf, SQ_HEAD_DIM, b.dLf, HD, M, SQ_HEAD_DIM, SQ_HEAD_DIM);
             g.a_bytes = (size_t)M * HD * es; g.b_bytes = (size_t)H * 64 * 64 * es;
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
             RUN(sq_launch_gemm(g, dtype, st));
@@ -184,10 +202,8 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         }
         // ---------------- summary branch ----------------
         if (lp) RUN(sq_k_cast_pad(b.dCs, HD, b.dCs_lp, dtype, HD, B, HD, st));
-        RUN(sq_k_transpose((const char*)W(L.c_w) + (size_t)SQ_HEAD_DIM * es, 2 * SQ_HEAD_DIM, b.wcT, SQ_HEAD_DIM, SQ_HEAD_DIM,
-                           SQ_HEAD_DIM, es, H, SQ_HEAD_DIM * 2 * SQ_HEAD_DIM, SQ_HEAD_DIM * SQ_HEAD_DIM, st));
         {   // dTs_h = dCs_h . Wc_h[:, 64:]
-            GemmArgs g = gemm(b.dCs_lp, HD, b.wcT, SQ_HEAD_DIM, b.dTs, HD, B, SQ_HEAD_DIM, SQ_HEAD_DIM);
+            GemmArgs g = gemm(b.dCs_lp, HD, b.wt[l].wc_ts, SQ_HEAD_DIM, b.dTs, HD, B, SQ_HEAD_DIM, SQ_HEAD_DIM);
             g.a_bytes = (size_t)B * HD * es; g.b_bytes = (size_t)H * 64 * 64 * es;
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
             RUN(sq_launch_gemm(g, dtype, st));
@@ -200,9 +216,8 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), b.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), b.red_ws, B, HD, st));
         RUN(sq_k_colsum(b.dSm, dtype, B, HD, HD, b.red_ws, Gp_(L.s_b), st));
         { GemmArgs g = gemm_tn(b.dSm, HD, w.Xbar[l], D, Gp_(L.s_w), D, HD, D, B); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-        RUN(tr(W(L.s_w), D, b.wT, HD, HD, D));                    // Ws [HD, D] -> [D, HD]
         {   // dXbar / N   (Xbar = mean_n X: every token of the slide receives dXbar / N)
-            GemmArgs g = gemm(b.dSm, HD, b.wT, HD, b.dXbar, D, B, D, HD);
+            GemmArgs g = gemm(b.dSm, HD, b.wt[l].s, HD, b.dXbar, D, B, D, HD);
             g.alpha = 1.0f / (float)N;
             RUN(sq_launch_gemm(g, dtype, st));
         }
@@ -210,9 +225,8 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), b.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.red_ws, M, HD, st));
         RUN(sq_k_colsum(b.dF, dtype, M, HD, HD, b.red_ws, Gp_(L.f_b), st));
         { GemmArgs g = gemm_tn(b.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-        RUN(tr(W(L.f_w), D, b.wT, HD, HD, D));                    // Wf [HD, D] -> [D, HD]
         {   // dXin = dF . Wf + dX1 (residual) + dXbar/N (per-slide row bias)
-            GemmArgs g = gemm(b.dF, HD, b.wT, HD, dXcur, D, M, D, HD);
+            GemmArgs g = gemm(b.dF, HD, b.wt[l].f, HD, dXcur, D, M, D, HD);
             g.res = dX1; g.ldres = D; g.rowbias = b.dXbar; g.ldrb = D; g.rows_per_group = N;
             g.C2 = lp ? (bf16_t*)dXcur_lp : nullptr; g.ldc2 = D;
             RUN(sq_launch_gemm(g, dtype, st));

@@ -45,11 +45,9 @@ def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6)):
 
 
 if __name__ == "__main__":
-    probe(6400, 1024, 1024, _lib.SQ_BF16, dbgs=(0, 1))
-    probe(6400, 1024, 1024, _lib.SQ_F32, tiles=(22, 11), dbgs=(0,))
-    probe(8192, 8192, 8192, _lib.SQ_BF16, tiles=(22,), dbgs=(0, 1))
-    probe(64, 1024, 1024, _lib.SQ_BF16, tiles=(0,), dbgs=(0,))
-    probe(64, 20820, 1024, _lib.SQ_BF16, tiles=(0, 12), dbgs=(0,))
-    probe(1024, 1024, 6400, _lib.SQ_BF16, tiles=(0,), dbgs=(0,))
-    probe(39200, 256, 2304, _lib.SQ_BF16, tiles=(0, 22, 21), dbgs=(0,))
-    probe(9800, 512, 4608, _lib.SQ_BF16, tiles=(0, 22, 11), dbgs=(0,))
+    probe(6400, 1024, 1024, _lib.SQ_BF16, tiles=(22,), dbgs=(0, 1))
+    probe(6400, 1024, 1024, _lib.SQ_F32, tiles=(22,), dbgs=(0,))
+    probe(8192, 8192, 8192, _lib.SQ_BF16, tiles=(22,), dbgs=(0,))
+    probe(39200, 256, 2304, _lib.SQ_BF16, tiles=(22, 21), dbgs=(0,))
+    probe(9800, 512, 4608, _lib.SQ_BF16, tiles=(22,), dbgs=(0,))
+    probe(156800, 128, 512, _lib.SQ_BF16, tiles=(0, 22), dbgs=(0,))
