@@ -208,9 +208,10 @@ int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const f
 /* Weight gradient of a linear layer: dW[N_out, N_in] (f32, lddw) = dY[T, N_out]^T . X[T, N_in], contracting
  * over the T token rows, straight from the token-major tensors (the `loss.backward()` of the nn.Linear call
  * sites above, src/vit.py:178).  dY (lddy) and X (ldx) are `dtype`; N_in % 8 == 0; lddy >= round_up(N_out, 8).
+ * dbias (optional, [N_out] f32): the bias gradient sum_t dY[t, :], computed by the same launch.
  * workspace: optional fp32 scratch enabling deterministic split-K over the tokens. */
-int sq_linear_weight_grad(int dtype, const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int n_out,
-                          int n_in, int n_tokens, void* workspace, size_t workspace_bytes, sq_stream_t stream);
+int sq_linear_weight_grad(int dtype, const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, float* dbias,
+                          int n_out, int n_in, int n_tokens, void* workspace, size_t workspace_bytes, sq_stream_t stream);
 
 #ifdef __cplusplus
 }

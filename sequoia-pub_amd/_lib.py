@@ -125,7 +125,7 @@ def _declare(lib):
     lib.sq_linear.restype = i32
     lib.sq_linear.argtypes = [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp, sz, vp]
     lib.sq_linear_weight_grad.restype = i32
-    lib.sq_linear_weight_grad.argtypes = [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, sz, vp]
+    lib.sq_linear_weight_grad.argtypes = [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, sz, vp]
     lib.sq_cast_f32_to_bf16.restype = i32
     lib.sq_cast_f32_to_bf16.argtypes = [vp, vp, sz, vp]
     for name, (res, args) in _OPTIONAL.items():

@@ -20,6 +20,7 @@ struct GemmArgs {
     const void* res = nullptr;        // [M, N] (ldres) f32 or bf16 (res_dtype)
     const float* gelu_grad_of = nullptr;  // [M, N] (ldgg): result *= GELU'(gelu_grad_of[m,n]) (backward of an activation)
     float alpha = 1.0f;               // scales the accumulator before the epilogue terms
+    float* colsum_a = nullptr;        // TN only, batch == 1: [M] sums of A's columns over the K contracted rows (bias gradient, unscaled)
     int M = 0, N = 0, K = 0;
     int lda = 0, ldb = 0, ldc = 0, ldc2 = 0, ldpre = 0, ldres = 0, ldrb = 0, ldgg = 0;
     int rows_per_group = 1;

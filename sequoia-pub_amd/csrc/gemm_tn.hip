@@ -53,8 +53,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BT - 1) / BT;
-    const int m0 = (blockIdx.x / tiles_n) * BT, n0 = (blockIdx.x % tiles_n) * BT;
+    // with a bias gradient requested, tiles_m extra blocks at the END of the grid sum A's columns instead of
+    // multiplying (appended, not interleaved: with N = 1024 block x lands on XCD x % 8 = its B column tile,
+    // which keeps every B tile in one XCD's L2)
+    const int tiles_n = (p.N + BT - 1) / BT, tiles_mn = ((p.M + BT - 1) / BT) * tiles_n;
+    const bool cs_block = (int)blockIdx.x >= tiles_mn;
+    const int m0 = (cs_block ? (int)blockIdx.x - tiles_mn : (int)blockIdx.x / tiles_n) * BT;
+    const int n0 = cs_block ? 0 : ((int)blockIdx.x % tiles_n) * BT;
     const int z = blockIdx.z;
 
     const T* Ab = reinterpret_cast<const T*>(p.A) + (long long)z * p.sA;
@@ -87,12 +92,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
         }
     };
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int li = lane & 15, lg = lane >> 4;
     // bf16 transpose-read addressing: lane (g = lane>>4, j = (lane>>2)&3, c = lane&3) hands the hardware the 8 bytes
     // at row 8g + j, columns 4c..4c+3 of a 16-column block; it receives column lane&15 of the group's four rows
@@ -107,6 +106,77 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
             tr_b[t] = row * ROWB + ((qb ^ kx) << 4) + ((c & 1) << 3);
         }
     }
+
+    if (cs_block) {
+        // colsum_a[m] = sum_k A[k, m]: the A tiles multiplied by a fragment of ones (every column of the 16x16
+        // result holds the same sums); waves with wn == 1 only help with the DMA
+        auto issue_a = [&](int kt, int buf) {
+            char* sa = smem + buf * (2 * TILE_BYTES);
+#pragma unroll
+            for (int j = 0; j < NINSTR; ++j) {
+                const int rbase = (j * 4 + wave) * ROWS_PER_INSTR;
+                const int row = rbase + lrow, k = kt * KR + row;
+                const int ca = m0 + (lchunk ^ key(row)) * (16 / (int)sizeof(T));
+                const uint32_t oa = (k < p.K && ca < p.M) ? (uint32_t)(((long long)k * p.lda + ca) * (long long)sizeof(T)) : OOB;
+                glds16(rsA, sa + rbase * ROWB, oa, 0);
+            }
+        };
+        f32x4 cs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt_lo < kt_hi) {
+            issue_a(kt_lo, 0);
+            __syncthreads();
+            for (int kt = kt_lo; kt < kt_hi; ++kt) {
+                const int cur = (kt - kt_lo) & 1;
+                if (kt + 1 < kt_hi) issue_a(kt + 1, cur ^ 1);
+                const char* sa = smem + cur * (2 * TILE_BYTES);
+                if (wn == 0) {
+                    if constexpr (LP) {
+                        bf16x8 ones;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const bf16x4 a0 = tr_read(sa + s * 32 * ROWB + tr_a[t]), a1 = tr_read(sa + (s * 32 + 4) * ROWB + tr_a[t]);
+                                cs[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), ones, cs[t], 0, 0, 0);
+                            }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) {
+                            const int row = 4 * s + lg, kx = (row & 3) << 2;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int ca = wm * 64 + t * 16 + li;
+                                const float fa = *reinterpret_cast<const float*>(sa + row * ROWB + (((ca >> 2) ^ kx) << 4) + ((ca & 3) << 2));
+                                cs[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, 1.0f, cs[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (wn == 0 && li == 0) {      // K-slices go behind the C partials in the split-K scratch
+            float* dst = p.splitk > 1 ? p.splitk_ws + (size_t)p.batch * p.splitk * (size_t)p.M * p.N + (size_t)blockIdx.y * p.M : p.colsum_a;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + lg * 4 + r;
+                    if (m < p.M) dst[m] = cs[i][r];
+                }
+        }
+        return;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
         const char* sa = smem + buf * (2 * TILE_BYTES);
@@ -214,6 +284,7 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
                (a.sA % epc) == 0 && (a.sB % epc) == 0, "gemm_tn: operands must be 16-byte aligned (lda=%d ldb=%d)", a.lda, a.ldb);
     SQ_REQUIRE(a.a_bytes > 0 && a.a_bytes < (1ull << 31) && a.b_bytes > 0 && a.b_bytes < (1ull << 31), "gemm_tn: operand extents must be < 2 GiB");
     SQ_REQUIRE(!a.conv, "gemm_tn: no convolution view");
+    SQ_REQUIRE(!a.colsum_a || a.batch == 1, "gemm_tn: colsum_a needs batch == 1");
     {
         auto al = [](const void* ptr, int ld, long long st, int elem) {
             return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
@@ -231,7 +302,7 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
         long long s = (512 + tiles * a.batch - 1) / (tiles * a.batch);
         if (s > nk / 2) s = nk / 2;
         if (s > 32) s = 32;
-        while (s > 1 && (size_t)s * a.M * a.N * a.batch * sizeof(float) > a.splitk_ws_bytes) --s;
+        while (s > 1 && (size_t)s * ((size_t)a.M * a.N * a.batch + (a.colsum_a ? a.M : 0)) * sizeof(float) > a.splitk_ws_bytes) --s;
         if (s > 1) a.splitk = (int)s;
     }
     int prof = -1;
@@ -242,7 +313,8 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
         prof = sq_prof_begin(name, 2.0 * a.M * (double)a.N * a.K * a.batch,
                              ((double)a.K * (a.M + a.N) * es + (double)a.M * a.N * 4.0) * a.batch, stream);
     }
-    dim3 grid((unsigned)tiles, a.splitk, a.batch), block(256);
+    const long long grid_x = tiles + (a.colsum_a ? (a.M + 127) / 128 : 0);      // + the column-sum blocks
+    dim3 grid((unsigned)grid_x, a.splitk, a.batch), block(256);
     if (dtype == SQ_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, block, 65536, stream, a);
     else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 65536, stream, a);
     SQ_LAUNCH_CHECK();

@@ -237,14 +237,15 @@ extern "C" int sq_linear(int dtype, const void* A, int lda, const void* W, int l
     return sq_launch_gemm(g, dtype, (hipStream_t)stream);
 }
 
-extern "C" int sq_linear_weight_grad(int dtype, const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int n_out,
-                                     int n_in, int n_tokens, void* workspace, size_t workspace_bytes, sq_stream_t stream) {
+extern "C" int sq_linear_weight_grad(int dtype, const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, float* dbias,
+                                     int n_out, int n_in, int n_tokens, void* workspace, size_t workspace_bytes, sq_stream_t stream) {
     SQ_REQUIRE(dY && X && dW, "linear_weight_grad: null pointer");
     GemmArgs g;
     const size_t es = sq_dtype_size(dtype);
     g.A = dY; g.lda = lddy; g.a_bytes = (size_t)n_tokens * lddy * es;
     g.B = X; g.ldb = ldx; g.b_bytes = (size_t)n_tokens * ldx * es;
     g.C = dW; g.ldc = lddw; g.M = n_out; g.N = n_in; g.K = n_tokens;
+    g.colsum_a = dbias;
     g.splitk_ws = (float*)workspace; g.splitk_ws_bytes = workspace_bytes;
     return sq_launch_gemm_tn(g, dtype, (hipStream_t)stream);
 }

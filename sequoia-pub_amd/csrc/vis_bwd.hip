@@ -4,7 +4,8 @@
 //
 // "dX = dY . W" products are NT GEMMs on a transposed copy of the (small) weight; "dW = dY^T . X"
 // products contract over tokens and run on the TN kernel straight from the token-major activations
-// the forward pass saved (no transposed activation copies).
+// the forward pass saved (no transposed activation copies); the same launch sums dY's columns into
+// the bias gradient.
 #include "elementwise.h"
 #include "gemm.h"
 #include "vis.h"
@@ -150,8 +151,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
 
     // ---------------- head: out = LN(mean_n X) Wh^T + bh ----------------
     RUN(sq_k_cast_pad(grad_out, G, b.dout_lp, dtype, Gp, B, G, st));
-    { GemmArgs g = gemm_tn(b.dout_lp, Gp, w.xn, D, Gp_(lay.head_w), D, G, D, B); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-    RUN(sq_k_colsum(grad_out, SQ_F32, B, G, G, b.red_ws, Gp_(lay.head_b), st));
+    { GemmArgs g = gemm_tn(b.dout_lp, Gp, w.xn, D, Gp_(lay.head_w), D, G, D, B); g.colsum_a = Gp_(lay.head_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
     { GemmArgs g = gemm(b.dout_lp, Gp, b.whT, Gp, b.dxn, D, B, D, Gp); RUN(sq_launch_gemm(g, dtype, st)); }
     RUN(sq_k_ln_rows_bwd(b.dxn, w.xm, Pf(lay.head_ln_g), nullptr, b.dxm, nullptr, Gp_(lay.head_ln_g), Gp_(lay.head_ln_b),
                          b.red_ws, B, D, st));
@@ -163,15 +163,13 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
     for (int l = c->depth - 1; l >= 0; --l) {
         const sq_vis_layer_offsets& L = lay.layer[l];
         // ---------------- FeedForward: X2 = GELU(LN(X1) W1^T + b1) W2^T + b2 + X1 ----------------
-        { GemmArgs g = gemm_tn(dXcur_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-        RUN(sq_k_colsum(dXcur, SQ_F32, M, D, D, b.red_ws, Gp_(L.ff2_b), st));
+        { GemmArgs g = gemm_tn(dXcur_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); g.colsum_a = Gp_(L.ff2_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         {   // dU = (dX2 . W2) * GELU'(U)
             GemmArgs g = gemm(dXcur_lp, D, b.wt[l].ff2, D, nullptr, D, M, D, D);
             g.C = b.dU; g.out_dtype = dtype; g.gelu_grad_of = w.U[l]; g.ldgg = D;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        { GemmArgs g = gemm_tn(b.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-        RUN(sq_k_colsum(b.dU, dtype, M, D, D, b.red_ws, Gp_(L.ff1_b), st));
+        { GemmArgs g = gemm_tn(b.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); g.colsum_a = Gp_(L.ff1_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         { GemmArgs g = gemm(b.dU, D, b.wt[l].ff1, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
         // dX1 = dX2 + dLN(dY)
         RUN(sq_k_ln_rows_bwd(b.dY, w.X1[l], Pf(L.ffln_g), dXcur, dXoth, lp ? (bf16_t*)dXoth_lp : nullptr, Gp_(L.ffln_g),
@@ -179,8 +177,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         float* dX1 = dXoth; void* dX1_lp = dXoth_lp;
 
         // ---------------- projection: X1 = O Wp^T + bp + X ----------------
-        { GemmArgs g = gemm_tn(dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-        RUN(sq_k_colsum(dX1, SQ_F32, M, D, D, b.red_ws, Gp_(L.proj_b), st));
+        { GemmArgs g = gemm_tn(dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); g.colsum_a = Gp_(L.proj_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         {   // dP = (dX1 . Wp) * GELU'(P)
             GemmArgs g = gemm(dX1_lp, D, b.wt[l].proj, D, nullptr, HD, M, HD, D);
             g.C = b.dP; g.out_dtype = dtype; g.gelu_grad_of = w.P[l]; g.ldgg = HD;
@@ -214,8 +211,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
             RUN(sq_launch_gemm_tn(g, dtype, st));
         }
         RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), b.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), b.red_ws, B, HD, st));
-        RUN(sq_k_colsum(b.dSm, dtype, B, HD, HD, b.red_ws, Gp_(L.s_b), st));
-        { GemmArgs g = gemm_tn(b.dSm, HD, w.Xbar[l], D, Gp_(L.s_w), D, HD, D, B); RUN(sq_launch_gemm_tn(g, dtype, st)); }
+        { GemmArgs g = gemm_tn(b.dSm, HD, w.Xbar[l], D, Gp_(L.s_w), D, HD, D, B); g.colsum_a = Gp_(L.s_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         {   // dXbar / N   (Xbar = mean_n X: every token of the slide receives dXbar / N)
             GemmArgs g = gemm(b.dSm, HD, b.wt[l].s, HD, b.dXbar, D, B, D, HD);
             g.alpha = 1.0f / (float)N;
@@ -223,8 +219,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         }
         // ---------------- local branch ----------------
         RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), b.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.red_ws, M, HD, st));
-        RUN(sq_k_colsum(b.dF, dtype, M, HD, HD, b.red_ws, Gp_(L.f_b), st));
-        { GemmArgs g = gemm_tn(b.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); RUN(sq_launch_gemm_tn(g, dtype, st)); }
+        { GemmArgs g = gemm_tn(b.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
         {   // dXin = dF . Wf + dX1 (residual) + dXbar/N (per-slide row bias)
             GemmArgs g = gemm(b.dF, HD, b.wt[l].f, HD, dXcur, D, M, D, HD);
             g.res = dX1; g.ldres = D; g.rowbias = b.dXbar; g.ldrb = D; g.rows_per_group = N;

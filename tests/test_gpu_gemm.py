@@ -107,12 +107,19 @@ def test_weight_grad_tn_kernel(T, NO, NI, dtype, ws_bytes):
     dYd[:, :NO] = dY.to(tdt)
     Xd = X.to("cuda", tdt).contiguous()
     dW = torch.full((NO, NI), float("nan"), device="cuda")
+    db = torch.full((NO,), float("nan"), device="cuda")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda") if ws_bytes else None
-    _lib.check(_lib.lib().sq_linear_weight_grad(dtype, _lib.ptr(dYd), ldy, _lib.ptr(Xd), NI, _lib.ptr(dW), NI, NO, NI, T,
+    _lib.check(_lib.lib().sq_linear_weight_grad(dtype, _lib.ptr(dYd), ldy, _lib.ptr(Xd), NI, _lib.ptr(dW), NI, _lib.ptr(db), NO, NI, T,
                                                 _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
     torch.cuda.synchronize()
     ref = dY.double().T @ X.double()
     assert rel_err(dW.cpu(), ref) < 1e-5, rel_err(dW.cpu(), ref)
+    # the bias gradient rides along in the same launch
+    assert rel_err(db.cpu(), dY.double().sum(0)) < 1e-5, rel_err(db.cpu(), dY.double().sum(0))
+    dW2 = torch.full((NO, NI), float("nan"), device="cuda")
+    _lib.check(_lib.lib().sq_linear_weight_grad(dtype, _lib.ptr(dYd), ldy, _lib.ptr(Xd), NI, _lib.ptr(dW2), NI, None, NO, NI, T,
+                                                _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
+    assert torch.equal(dW, dW2)
 
 
 def test_bad_arguments_fail_loudly():
