@@ -53,13 +53,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // with a bias gradient requested, tiles_m extra blocks at the END of the grid sum A's columns instead of
-    // multiplying (appended, not interleaved: with N = 1024 block x lands on XCD x % 8 = its B column tile,
-    // which keeps every B tile in one XCD's L2)
-    const int tiles_n = (p.N + BT - 1) / BT, tiles_mn = ((p.M + BT - 1) / BT) * tiles_n;
-    const bool cs_block = (int)blockIdx.x >= tiles_mn;
-    const int m0 = (cs_block ? (int)blockIdx.x - tiles_mn : (int)blockIdx.x / tiles_n) * BT;
-    const int n0 = cs_block ? 0 : ((int)blockIdx.x % tiles_n) * BT;
+    // with a bias gradient requested, round_up(tiles_m, 8) extra blocks at the FRONT of the grid sum A's columns
+    // instead of multiplying (they are latency-bound, so they must not form the tail; a multiple of 8 keeps
+    // block x of the product on XCD x % 8 = its B column tile when N = 1024, i.e. every B tile in one L2)
+    const int tiles_n = (p.N + BT - 1) / BT, tiles_m = (p.M + BT - 1) / BT;
+    const int cs_blocks = p.colsum_a ? (tiles_m + 7) / 8 * 8 : 0;
+    const bool cs_block = (int)blockIdx.x < cs_blocks;
+    if (cs_block && (int)blockIdx.x >= tiles_m) return;
+    const int bx = (int)blockIdx.x - cs_blocks;
+    const int m0 = (cs_block ? (int)blockIdx.x : bx / tiles_n) * BT;
+    const int n0 = cs_block ? 0 : (bx % tiles_n) * BT;
     const int z = blockIdx.z;
 
     const T* Ab = reinterpret_cast<const T*>(p.A) + (long long)z * p.sA;
@@ -298,8 +301,11 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
     const int nk = (a.K + kr - 1) / kr;
     const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     a.splitk = 1;
+    const long long cs_blocks = a.colsum_a ? ((a.M + 127) / 128 + 7) / 8 * 8 : 0;
     if (a.splitk_ws && tiles * a.batch < 256 && nk >= 4) {
-        long long s = (512 + tiles * a.batch - 1) / (tiles * a.batch);
+        // 2 blocks (64 KiB LDS each) per CU x 256 CUs: the whole grid should be resident at once
+        long long s = 512 / ((tiles + cs_blocks) * a.batch);
+        if (s < 1) s = 1;
         if (s > nk / 2) s = nk / 2;
         if (s > 32) s = 32;
         while (s > 1 && (size_t)s * ((size_t)a.M * a.N * a.batch + (a.colsum_a ? a.M : 0)) * sizeof(float) > a.splitk_ws_bytes) --s;
@@ -313,7 +319,7 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
         prof = sq_prof_begin(name, 2.0 * a.M * (double)a.N * a.K * a.batch,
                              ((double)a.K * (a.M + a.N) * es + (double)a.M * a.N * 4.0) * a.batch, stream);
     }
-    const long long grid_x = tiles + (a.colsum_a ? (a.M + 127) / 128 : 0);      // + the column-sum blocks
+    const long long grid_x = tiles + cs_blocks;
     dim3 grid((unsigned)grid_x, a.splitk, a.batch), block(256);
     if (dtype == SQ_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, block, 65536, stream, a);
     else hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 65536, stream, a);

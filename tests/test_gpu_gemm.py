@@ -119,7 +119,7 @@ def test_weight_grad_tn_kernel(T, NO, NI, dtype, ws_bytes):
     dW2 = torch.full((NO, NI), float("nan"), device="cuda")
     _lib.check(_lib.lib().sq_linear_weight_grad(dtype, _lib.ptr(dYd), ldy, _lib.ptr(Xd), NI, _lib.ptr(dW2), NI, None, NO, NI, T,
                                                 _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
-    assert torch.equal(dW, dW2)
+    assert rel_err(dW2.cpu(), dW.cpu()) < 1e-6          # (the K-slice count, hence the summation order, may differ)
 
 
 def test_bad_arguments_fail_loudly():
