@@ -22,6 +22,7 @@ extern "C" {
 #endif
 
 typedef void* sq_stream_t; /* hipStream_t */
+typedef void* sq_event_t;  /* hipEvent_t */
 
 #define SQ_DTYPE_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
 #define SQ_DTYPE_BF16 1 /* bf16 MFMA, fp32 accumulate: perf mode              */
@@ -96,6 +97,18 @@ size_t sq_vis_backward_workspace_bytes(const sq_vis_config* cfg, int dtype, int 
 int sq_vis_backward(const sq_vis_config* cfg, int dtype, const float* params, const void* params_lp,
                     const float* grad_out, float* grad_params, float* grad_x, int batch, void* fwd_workspace,
                     size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, sq_stream_t stream);
+
+/* Data-parallel training (src/main.py DDP-less reference; BASELINE config 4): the flat gradient splits into
+ * depth + 1 contiguous buckets [lo, hi) (elements), listed in the order the backward pass finishes them (head
+ * first, then layers last to first; layer 0's bucket also holds pos_emb1D).  sq_vis_backward_buckets records
+ * bucket_events[i] (hipEvent_t) on `stream` as soon as bucket i is final, so the caller can start that bucket's
+ * RCCL all-reduce on another stream while the rest of the backward pass still runs.  Returns the bucket count. */
+int sq_vis_grad_buckets(const sq_vis_config* cfg, int64_t* lo, int64_t* hi, int cap);
+int sq_vis_backward_buckets(const sq_vis_config* cfg, int dtype, const float* params, const void* params_lp,
+                            const float* grad_out, float* grad_params, float* grad_x, int batch, void* fwd_workspace,
+                            size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, sq_stream_t stream,
+                            const sq_event_t* bucket_events, int n_bucket_events);
+
 
 /* ------------------------------------------------------------------------------
  * Softmax ViT baseline  (src/vit.py:49-115: Attention :49-74, Transformer :76-89, ViT :91-115;

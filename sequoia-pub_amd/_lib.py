@@ -89,6 +89,11 @@ def _declare(lib):
     lib.sq_vis_backward_workspace_bytes.argtypes = [ctypes.POINTER(VisConfig), i32, i32]
     lib.sq_vis_backward.restype = i32
     lib.sq_vis_backward.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, vp, i32, vp, sz, vp, sz, vp]
+    lib.sq_vis_backward_buckets.restype = i32
+    lib.sq_vis_backward_buckets.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, vp, i32, vp, sz, vp, sz, vp,
+                                            ctypes.POINTER(vp), i32]
+    lib.sq_vis_grad_buckets.restype = i32
+    lib.sq_vis_grad_buckets.argtypes = [ctypes.POINTER(VisConfig), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), i32]
     lib.sq_train_scratch_bytes.restype = sz
     lib.sq_train_scratch_bytes.argtypes = [i32]
     f32 = ctypes.c_float

@@ -76,16 +76,44 @@ extern "C" size_t sq_vis_backward_workspace_bytes(const sq_vis_config* c, int dt
     return b.bytes;
 }
 
+extern "C" int sq_vis_grad_buckets(const sq_vis_config* c, int64_t* lo, int64_t* hi, int cap) {
+    sq_vis_layout lay;
+    if (int e = sq_vis_layout_init(c, &lay)) return e;
+    SQ_REQUIRE(lo && hi && cap >= c->depth + 1, "vis_grad_buckets: need room for %d buckets", c->depth + 1);
+    lo[0] = lay.head_ln_g; hi[0] = lay.total;                     // the head's gradients are complete first
+    for (int i = 0; i < c->depth; ++i) {                          // then the layers, last to first
+        const int l = c->depth - 1 - i;
+        lo[1 + i] = l == 0 ? 0 : lay.layer[l].f_w;                // pos_emb1D (finished last) rides with layer 0
+        hi[1 + i] = l + 1 < c->depth ? lay.layer[l + 1].f_w : lay.head_ln_g;
+    }
+    return c->depth + 1;
+}
+
 extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* params, const void* params_lp,
                                const float* grad_out, float* grad_params, float* grad_x, int B, void* fwd_workspace,
                                size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes,
                                sq_stream_t stream_) {
+    return sq_vis_backward_buckets(c, dtype, params, params_lp, grad_out, grad_params, grad_x, B, fwd_workspace, fwd_workspace_bytes,
+                                   bwd_workspace, bwd_workspace_bytes, stream_, nullptr, 0);
+}
+
+extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const float* params, const void* params_lp,
+                                       const float* grad_out, float* grad_params, float* grad_x, int B, void* fwd_workspace,
+                                       size_t fwd_workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes,
+                                       sq_stream_t stream_, const sq_event_t* bucket_events, int n_bucket_events) {
     sq_vis_layout lay;
     if (int e = sq_vis_layout_init(c, &lay)) return e;
     hipStream_t st = (hipStream_t)stream_;
     SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16, "vis_backward: dtype %d", dtype);
     SQ_REQUIRE(params && grad_out && grad_params && fwd_workspace && bwd_workspace, "vis_backward: null pointer");
     SQ_REQUIRE(dtype == SQ_F32 || params_lp, "vis_backward: bf16 mode needs the bf16 parameter shadow");
+    SQ_REQUIRE(n_bucket_events == 0 || (bucket_events && n_bucket_events == c->depth + 1),
+               "vis_backward: %d bucket events given, sq_vis_grad_buckets has %d", n_bucket_events, c->depth + 1);
+    auto bucket_done = [&](int i) {                               // bucket i of sq_vis_grad_buckets is final from here on
+        if (n_bucket_events == 0) return (int)SQ_OK;
+        SQ_HIP_CHECK(hipEventRecord((hipEvent_t)bucket_events[i], st));
+        return (int)SQ_OK;
+    };
     VisBufs w;
     sq_vis_bufs(*c, dtype, B, 1, (char*)fwd_workspace, &w);
     BwdBufs b;
@@ -155,6 +183,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
     { GemmArgs g = gemm(b.dout_lp, Gp, b.whT, Gp, b.dxn, D, B, D, Gp); RUN(sq_launch_gemm(g, dtype, st)); }
     RUN(sq_k_ln_rows_bwd(b.dxn, w.xm, Pf(lay.head_ln_g), nullptr, b.dxm, nullptr, Gp_(lay.head_ln_g), Gp_(lay.head_ln_b),
                          b.red_ws, B, D, st));
+    RUN(bucket_done(0));
     RUN(sq_k_bcast_rows(b.dxm, 1.0f / (float)N, b.dXa, lp ? (bf16_t*)b.dXa_lp : nullptr, B, N, D, st));
 
     float* dXcur = b.dXa; void* dXcur_lp = b.dXa_lp;
@@ -220,6 +249,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         // ---------------- local branch ----------------
         RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), b.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.red_ws, M, HD, st));
         { GemmArgs g = gemm_tn(b.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
+        if (l > 0) RUN(bucket_done(c->depth - l));
         {   // dXin = dF . Wf + dX1 (residual) + dXbar/N (per-slide row bias)
             GemmArgs g = gemm(b.dF, HD, b.wt[l].f, HD, dXcur, D, M, D, HD);
             g.res = dX1; g.ldres = D; g.rowbias = b.dXbar; g.ldrb = D; g.rows_per_group = N;
@@ -228,6 +258,7 @@ extern "C" int sq_vis_backward(const sq_vis_config* c, int dtype, const float* p
         }
     }
     RUN(sq_k_batch_sum(dXcur, gp + lay.pos, B, N * D, st));       // pos_emb1D is added to every slide
+    RUN(bucket_done(c->depth));
     if (grad_x) SQ_HIP_CHECK(hipMemcpyAsync(grad_x, dXcur, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
 #undef RUN
     (void)Gp;

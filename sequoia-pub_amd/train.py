@@ -31,8 +31,22 @@ def smape(A, F):
 # ---------------------------------------------------------------------------------------------
 # device-side pieces
 # ---------------------------------------------------------------------------------------------
-def vis_backward(model, grad_out, batch, need_x_grad):
-    """sq_vis_backward on the workspace the matching forward saved.  Returns (grad_flat, grad_x)."""
+def grad_buckets(model):
+    """[(lo, hi)] element ranges of the flat gradient in the order the backward pass completes them
+    (sq_vis_grad_buckets); models without bucket support (the ViT baseline) are one bucket."""
+    if model._C_BWD != "sq_vis_backward":
+        return [(0, model.flat.numel())]
+    cap = model.cfg.depth + 1
+    lo, hi = (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
+    n = _lib.lib().sq_vis_grad_buckets(ctypes.byref(model.cfg), lo, hi, cap)
+    if n < 0:
+        _lib.check(n)
+    return [(int(lo[i]), int(hi[i])) for i in range(n)]
+
+
+def vis_backward(model, grad_out, batch, need_x_grad, bucket_events=None):
+    """sq_vis_backward on the workspace the matching forward saved.  Returns (grad_flat, grad_x).
+    bucket_events: torch.cuda.Event per grad_buckets() entry, recorded mid-pass as each bucket becomes final."""
     dev = model.flat.device
     grad_out = grad_out.to(dev, torch.float32).contiguous()
     need = getattr(_lib.lib(), model._C_BWS)(ctypes.byref(model.cfg), model.compute_dtype, batch)
@@ -44,10 +58,17 @@ def vis_backward(model, grad_out, batch, need_x_grad):
     gx = torch.empty(batch, model.cfg.num_clusters, model._dim(), device=dev) if need_x_grad else None
     ws = model._ws
     with torch.cuda.device(dev):
-        _lib.check(getattr(_lib.lib(), model._C_BWD)(
-            ctypes.byref(model.cfg), model.compute_dtype, _lib.ptr(model.flat), _lib.ptr(model._params_lp()),
-            _lib.ptr(grad_out), _lib.ptr(gflat), _lib.ptr(gx), batch, _lib.ptr(ws), ws.numel(),
-            _lib.ptr(model._bws), model._bws.numel(), _lib.stream_ptr(dev)))
+        args = (ctypes.byref(model.cfg), model.compute_dtype, _lib.ptr(model.flat), _lib.ptr(model._params_lp()),
+                _lib.ptr(grad_out), _lib.ptr(gflat), _lib.ptr(gx), batch, _lib.ptr(ws), ws.numel(),
+                _lib.ptr(model._bws), model._bws.numel(), _lib.stream_ptr(dev))
+        if bucket_events is not None and model._C_BWD == "sq_vis_backward":
+            handles = (ctypes.c_void_p * len(bucket_events))(*[e.cuda_event for e in bucket_events])
+            _lib.check(_lib.lib().sq_vis_backward_buckets(*args, handles, len(bucket_events)))
+        else:
+            _lib.check(getattr(_lib.lib(), model._C_BWD)(*args))
+            if bucket_events is not None:
+                for e in bucket_events:
+                    e.record(torch.cuda.current_stream(dev))
     return gflat, gx
 
 
@@ -96,6 +117,18 @@ class FusedTrainStep:
         self.metrics = metrics
         self.exp_avg = torch.zeros_like(model.flat.detach())
         self.exp_avg_sq = torch.zeros_like(model.flat.detach())
+        # gradient all-reduce overlapped with the backward pass: one bucket per layer (+ head), each reduced on
+        # a side stream as soon as the backward pass has recorded its event.  SQ_FORCE_BUCKETS=1 exercises the
+        # same path on a single rank.
+        self.overlap = world_size > 1 or os.environ.get("SQ_FORCE_BUCKETS") == "1"
+        if self.overlap:
+            dev = model.flat.device
+            self.buckets = grad_buckets(model)
+            self.comm_stream = torch.cuda.Stream(device=dev)
+            self.events = [torch.cuda.Event() for _ in self.buckets]
+            with torch.cuda.device(dev):
+                for e in self.events:
+                    e.record()              # instantiates the hipEvent_t the C side records into
 
     def step(self, x, target):
         m = self.model
@@ -105,9 +138,18 @@ class FusedTrainStep:
         n_global = pred.numel() * self.world
         loss, gpred = mse_loss_grad(m, pred, target, grad_scale=2.0 / n_global)
         mets = batch_metrics(m, pred, target) if self.metrics else None
-        gflat, _ = vis_backward(m, gpred, B, False)
-        if self.world > 1:
-            dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
+        if not self.overlap:
+            gflat, _ = vis_backward(m, gpred, B, False)
+        else:
+            main = torch.cuda.current_stream(dev)
+            gflat, _ = vis_backward(m, gpred, B, False, bucket_events=self.events)
+            reduce_ = dist.is_available() and dist.is_initialized()
+            for (lo, hi), ev in zip(self.buckets, self.events):
+                self.comm_stream.wait_event(ev)
+                if reduce_:
+                    with torch.cuda.stream(self.comm_stream):
+                        dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
+            main.wait_stream(self.comm_stream)
         self.step_count += 1
         lp = m._params_lp()
         with torch.no_grad():

@@ -42,6 +42,22 @@ def test_layout_is_aligned_and_dense():
         assert getattr(lay.layer[0], f) % 8 == 0              # 16-byte aligned in bf16 as well
 
 
+def test_gradient_buckets_tile_the_flat_buffer():
+    """The all-reduce buckets (completion order: head, layers last to first) cover every gradient exactly once."""
+    cfg = _lib.VisConfig(1024, 6, 16, 20820, 100)
+    lay = vis_layout(cfg)
+    cap = cfg.depth + 1
+    lo, hi = (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
+    assert _lib.lib().sq_vis_grad_buckets(ctypes.byref(cfg), lo, hi, cap) == cap
+    spans = sorted((lo[i], hi[i]) for i in range(cap))
+    assert spans[0][0] == 0 and spans[-1][1] == lay.total
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 == b0
+    assert (lo[0], hi[0]) == (lay.head_ln_g, lay.total)                    # head first
+    assert lo[cap - 1] == 0 and hi[cap - 1] == lay.layer[1].f_w            # layer 0 (+ pos_emb1D) last
+    assert _lib.lib().sq_vis_grad_buckets(ctypes.byref(cfg), lo, hi, 3) < 0
+
+
 def test_bad_config_reports_error():
     cfg = _lib.VisConfig(100, 6, 16, 10, 100)                 # D not a multiple of 64
     lay = _lib.VisLayout()

@@ -63,6 +63,34 @@ def test_three_fused_adamw_steps_match_reference(golden_dir):
         np.testing.assert_allclose(after[k[4:]].cpu().numpy(), z[k], rtol=1e-3, atol=3e-5, err_msg=k)
 
 
+def test_bucketed_overlapped_allreduce_path_matches(golden_dir, monkeypatch):
+    """The data-parallel step (per-bucket events recorded mid-backward, all-reduce on a side stream) on a
+    one-rank RCCL group must reproduce the plain step bit for bit."""
+    _lib.require_gpu()
+    import torch.distributed as dist
+    z, sd, m = _tiny(golden_dir)
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["target"]).cuda()
+    plain = sq_train.FusedTrainStep(m, lr=1e-3)
+    ref_losses = [float(plain.step(x, y)[0]) for _ in range(3)]
+    ref_flat = m.flat.detach().clone()
+    z, sd, m2 = _tiny(golden_dir)
+    monkeypatch.setenv("SQ_FORCE_BUCKETS", "1")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+        created = True
+    try:
+        st = sq_train.FusedTrainStep(m2, lr=1e-3)
+        assert st.overlap and len(st.buckets) == m2.cfg.depth + 1
+        losses = [float(st.step(x, y)[0]) for _ in range(3)]
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert losses == ref_losses
+    assert torch.equal(m2.flat.detach(), ref_flat)
+
+
 def test_torch_optimizer_through_autograd_matches_fused(golden_dir):
     _lib.require_gpu()
     z, sd, m = _tiny(golden_dir)
