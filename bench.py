@@ -251,9 +251,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "vis_train"), choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=64, help="slides per GPU per step")
-    ap.add_argument("--slides", type=int, default=2, help="pipeline workload: slides per GPU per step")
+    ap.add_argument("--slides", type=int, default=8, help="pipeline workload: slides per GPU per step")
     ap.add_argument("--patches", type=int, default=1000, help="pipeline workload: patches per slide")
-    ap.add_argument("--sub-batch", type=int, default=100, help="pipeline workload: patches per ResNet launch group")
+    ap.add_argument("--sub-batch", type=int, default=500, help="pipeline workload: patches per ResNet launch group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -13,11 +13,12 @@ from .kmeans import kmeans_fit_batch
 
 
 class SlidePipeline:
-    def __init__(self, resnet, vis, n_clusters=100, sub_batch=100):
+    def __init__(self, resnet, vis, n_clusters=100, sub_batch=500):
         self.resnet = resnet
         self.vis = vis
         self.n_clusters = n_clusters
         self.sub_batch = sub_batch
+        self._side = None
 
     @torch.no_grad()
     def embed(self, patches_u8):
@@ -33,15 +34,40 @@ class SlidePipeline:
     @torch.no_grad()
     def __call__(self, slides_u8):
         """slides_u8: list of [n_i, S, S, 3] uint8 tensors, or one [S, n, S, S, 3] tensor.
-        Returns dict(pred [S, G], cluster_features [S, 100, D], labels list)."""
-        feats = [self.embed(p) for p in slides_u8]
-        same = all(f.shape[0] == feats[0].shape[0] for f in feats)
-        if same:
-            cf, labels = self.cluster(torch.stack(feats))
-            labels = list(labels)
-        else:                                   # ragged patch counts: one k-Means call per slide
-            outs = [self.cluster(f.unsqueeze(0)) for f in feats]
-            cf = torch.cat([o[0] for o in outs])
-            labels = [o[1][0] for o in outs]
+        Returns dict(pred [S, G], cluster_features [S, 100, D], labels list).
+
+        The k-Means of slide i (small grids, a host check of the convergence flags every few Lloyd
+        iterations) runs on a side stream while the ResNet of slide i+1 -- already enqueued on the main
+        stream -- keeps the chip busy, so only the last slide's clustering is exposed."""
+        dev = self.vis.flat.device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
+        feats, cfs, labels = [], [], []
+
+        def cluster_on_side(f, ev):
+            side.wait_event(ev)
+            f.record_stream(side)
+            with torch.cuda.stream(side):
+                cf, lab = self.cluster(f.unsqueeze(0))
+            cf.record_stream(main)
+            lab.record_stream(main)
+            cfs.append(cf)
+            labels.append(lab[0])
+
+        pending = None
+        for p in slides_u8:
+            f = self.embed(p)                      # enqueued first: the GPU has this to chew on ...
+            ev = torch.cuda.Event()
+            ev.record(main)
+            feats.append(f)
+            if pending is not None:
+                cluster_on_side(*pending)          # ... while the host drives the previous slide's k-Means
+            pending = (f, ev)
+        if pending is not None:
+            cluster_on_side(*pending)
+        main.wait_stream(side)
+        cf = torch.cat(cfs)
         pred = self.vis(cf)
         return dict(pred=pred, cluster_features=cf, labels=labels, features=feats)

@@ -138,9 +138,10 @@ class ResNet50(nn.Module):
         return self._run(x_f32=x.to(dev, torch.float32).contiguous())
 
     @torch.no_grad()
-    def extract_patches_u8(self, patches, sub_batch=64):
+    def extract_patches_u8(self, patches, sub_batch=500):
         """uint8 HWC patches [n, S, S, 3] -> f32 [n, 2048]; fuses compute_features_hdf5.py:119-120's transform.
-        Patches are processed in sub-batches so the activations stay inside the 256 MiB Infinity Cache."""
+        Patches go through in sub-batches of <= 500 (the 2 GiB buffer-descriptor limit of the conv1 im2col
+        matrix); larger sub-batches measured faster (38.1 slides/s at 500 vs 34.9 at 200) -- longer grids, fewer tails."""
         dev = self.conv1.weight.device
         patches = torch.as_tensor(patches)
         outs = []
