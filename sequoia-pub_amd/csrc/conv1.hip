@@ -1,0 +1,206 @@
+// ResNet-50 stem in one kernel (bf16 mode):
+//   uint8 HWC patch -> /255 -> ImageNet normalise -> conv1 7x7 stride 2 pad 3 (3 -> 64, BN folded) -> ReLU
+//   -> MaxPool2d(3, stride 2, padding 1)  ==  src/resnet.py:157-160 after compute_features_hdf5.py:119-120.
+//
+// The im2col route writes (and the GEMM re-reads) a [n*112*112, 152] matrix: 3.8 GB per 500 patches against
+// 75 MB of pixels in and 100 MB of pooled activations out.  Here a block owns a 17 x 17 tile of conv outputs
+// (what an 8 x 8 tile of pooled outputs needs) and never leaves the chip in between:
+//   * the 39 x 40 input window is normalised once into LDS as [row][col][4 ch] bf16 (channel 3 = 0), so the
+//     two pixels x 4 channels an MFMA lane needs for 8 consecutive k are one aligned ds_read_b128;
+//   * K is laid out ky-major, 8 kx (kx = 7 has zero weight) x 4 ch = 32 per ky: K = 224 instead of 147,
+//     traded for aligned 16-byte fragment reads (the stem is not MFMA-bound);
+//   * the weights live in registers for the whole (persistent) block: 14 k-steps x 4 VGPRs per wave;
+//   * waves are 2 (M: 5 tiles of 32 conv pixels) x 2 (N: 32 channels); the conv tile goes to LDS as bf16 after
+//     bias + ReLU and the 3 x 3 max is taken from there (rounding is monotonic, so pooling bf16 values equals
+//     rounding after pooling).
+#include "gemm.h"
+
+namespace {
+
+constexpr int TP = 8;                    // pooled tile edge
+constexpr int TC = 2 * TP + 1;           // conv tile edge (17)
+constexpr int RW = 40;                   // staged input row pitch in pixels (39 needed + kx = 7 slot)
+constexpr int RH = 2 * TC + 5;           // staged input rows (39)
+constexpr int IN_BYTES = RH * RW * 8;    // 12480
+constexpr int MT = 10;                   // 32-row MFMA tiles covering the 289 conv pixels
+constexpr int CROW = 144;                // bytes per conv pixel in LDS (64 ch bf16 + 16 pad: conflict-free b16 writes)
+constexpr int COUT_BYTES = MT * 32 * CROW;
+constexpr int LUT_BYTES = 3 * 256 * 2;
+constexpr int W_LD = 152;                // packed conv1 weight row: k = (ky*7 + kx)*3 + c, zero padded (resnet.hip)
+
+struct Conv1Args {
+    const uint8_t* u8;          // [n, S, S, 3] or null
+    const float* f32;           // [n, 3, S, S] normalised, or null
+    const bf16_t* w;            // [64, 152]
+    const float* bias;          // [64]
+    bf16_t* out;                // [n, S/4, S/4, 64]
+    int n, S, tiles_per_side, tiles;
+};
+
+__global__ __launch_bounds__(256) void conv1_pool_kernel(const Conv1Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_in = smem;
+    char* s_out = smem + IN_BYTES;
+    bf16_t* s_lut = reinterpret_cast<bf16_t*>(smem + IN_BYTES + COUT_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, g = lane >> 5;
+
+    for (int i = tid; i < 3 * 256; i += 256) {     // the reference's fp32 transform, then the bf16 operand rounding
+        const int c = i >> 8, v = i & 255;
+        const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f), sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+        s_lut[i] = f32_to_bf16(((float)v / 255.0f - mean) / sd);
+    }
+
+    // weight fragments: k-step t = (ky, h); lane (n = l31, g) holds k = ky*32 + h*16 + g*8 + e  ->  kx = 4h + 2g + (e>>2), c = e&3
+    bf16x8 wf[14];
+    {
+        const bf16_t* wr = p.w + (size_t)(wn * 32 + l31) * W_LD;
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            const int ky = t >> 1, h = t & 1;
+            union { bf16x8 v; uint16_t u[8]; } f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kx = 4 * h + 2 * g + (e >> 2), c = e & 3;
+                f.u[e] = (kx < 7 && c < 3) ? wr[(ky * 7 + kx) * 3 + c] : (uint16_t)0;
+            }
+            wf[t] = f.v;
+        }
+    }
+    const float bias = p.bias[wn * 32 + l31];
+    __syncthreads();                               // look-up table ready
+
+    // A-fragment base addresses: conv pixel m = wm*160 + i*32 + l31 -> (oy, ox) in the 17 x 17 tile
+    int a_off[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int m = wm * 160 + i * 32 + l31;
+        if (m >= TC * TC) m = 0;                   // rows past the tile: computed, never read
+        const int oy = m / TC, ox = m - oy * TC;
+        a_off[i] = ((2 * oy) * RW + 2 * ox + 2 * g) * 8;
+    }
+
+    const int S = p.S, OH = S / 2, PH = S / 4;
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const int img = tile / (p.tiles_per_side * p.tiles_per_side);
+        const int tt = tile - img * p.tiles_per_side * p.tiles_per_side;
+        const int ty = tt / p.tiles_per_side, tx = tt - ty * p.tiles_per_side;
+        const int iy0 = 4 * TP * ty - 5, ix0 = 4 * TP * tx - 5;     // input pixel of staged (0, 0)
+
+        // ---- stage the normalised input window
+        for (int idx = tid; idx < RH * RW; idx += 256) {
+            const int r = idx / RW, q = idx - r * RW;
+            const int iy = iy0 + r, ix = ix0 + q;
+            uint32_t lo = 0, hi = 0;
+            if ((unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S) {
+                if (p.u8) {
+                    const uint8_t* px = p.u8 + (((size_t)img * S + iy) * S + ix) * 3;
+                    lo = (uint32_t)s_lut[px[0]] | ((uint32_t)s_lut[256 + px[1]] << 16);
+                    hi = (uint32_t)s_lut[512 + px[2]];
+                } else {
+                    const float* px = p.f32 + ((size_t)img * 3 * S + iy) * S + ix;
+                    lo = pack_bf16x2(px[0], px[(size_t)S * S]);
+                    hi = (uint32_t)f32_to_bf16(px[2 * (size_t)S * S]);
+                }
+            }
+            *reinterpret_cast<u32x2*>(s_in + idx * 8) = u32x2{lo, hi};
+        }
+        __syncthreads();
+
+        // ---- 17 x 17 x 64 conv tile on the MFMA
+        f32x16 acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            const int ky = t >> 1, h = t & 1;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(s_in + a_off[i] + (ky * RW + 4 * h) * 8);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), wf[t], acc[i], 0, 0, 0);
+            }
+        }
+        // bias + ReLU -> bf16 conv tile in LDS.  C/D layout: col = l31 (channel), row = (r&3) + 8*(r>>2) + 4*g
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 160 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const float v = fmaxf(acc[i][r] + bias, 0.f);
+                *reinterpret_cast<bf16_t*>(s_out + m * CROW + (wn * 32 + l31) * 2) = f32_to_bf16(v);
+            }
+        __syncthreads();
+
+        // ---- 3 x 3 stride-2 max over the conv tile: thread = (pooled pixel, 16 channels)
+        {
+            const int pp = tid >> 2, cg = tid & 3;
+            const int py = pp >> 3, px = pp & 7;
+            float best[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) best[e] = -INFINITY;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cy = 2 * py + dy, cx = 2 * px + dx;                  // conv pixel inside the tile
+                    const int oy = 2 * TP * ty - 1 + cy, ox = 2 * TP * tx - 1 + cx;   // and in the image (the pool's -inf padding)
+                    if (oy >= 0 && ox >= 0 && oy < OH && ox < OH) {
+                        const char* src = s_out + (cy * TC + cx) * CROW + cg * 32;
+                        const u32x4 a = *reinterpret_cast<const u32x4*>(src), b = *reinterpret_cast<const u32x4*>(src + 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            best[2 * e] = fmaxf(best[2 * e], __uint_as_float(a[e] << 16));
+                            best[2 * e + 1] = fmaxf(best[2 * e + 1], __uint_as_float(a[e] & 0xffff0000u));
+                            best[8 + 2 * e] = fmaxf(best[8 + 2 * e], __uint_as_float(b[e] << 16));
+                            best[8 + 2 * e + 1] = fmaxf(best[8 + 2 * e + 1], __uint_as_float(b[e] & 0xffff0000u));
+                        }
+                    }
+                }
+            u32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {      // exact: the values are bf16 already
+                o0[e] = (__float_as_uint(best[2 * e]) >> 16) | (__float_as_uint(best[2 * e + 1]) & 0xffff0000u);
+                o1[e] = (__float_as_uint(best[8 + 2 * e]) >> 16) | (__float_as_uint(best[8 + 2 * e + 1]) & 0xffff0000u);
+            }
+            bf16_t* dst = p.out + (((size_t)img * PH + TP * ty + py) * PH + TP * tx + px) * 64 + cg * 16;
+            *reinterpret_cast<u32x4*>(dst) = o0;
+            *reinterpret_cast<u32x4*>(dst + 8) = o1;
+        }
+        // the next tile's staging only touches s_in (all MFMA reads are behind the barrier above); its conv
+        // tile is written after the next barrier, by which time every thread has finished pooling this one
+    }
+}
+
+}  // namespace
+
+// out [n, S/4, S/4, 64] bf16 = maxpool(relu(conv1(normalise(patches)) + bias)); S a multiple of 32
+int sq_launch_conv1_pool_bf16(const uint8_t* u8, const float* f32_nchw, const bf16_t* w152, const float* bias, bf16_t* out,
+                              int n, int S, hipStream_t stream) {
+    SQ_REQUIRE(S % (4 * TP) == 0 && n >= 1, "conv1_pool: patch size %d must be a multiple of %d", S, 4 * TP);
+    Conv1Args a;
+    a.u8 = u8; a.f32 = f32_nchw; a.w = w152; a.bias = bias; a.out = out; a.n = n; a.S = S;
+    a.tiles_per_side = S / (4 * TP);
+    const long long tiles = (long long)n * a.tiles_per_side * a.tiles_per_side;
+    SQ_REQUIRE(tiles < (1ll << 31), "conv1_pool: too many tiles");
+    a.tiles = (int)tiles;
+    const size_t lds = IN_BYTES + COUT_BYTES + LUT_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv1_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int grid = (int)(tiles < 512 ? tiles : 512);      // persistent: 2 blocks per CU keep their weights in registers
+    int prof = -1;
+    if (sq_prof_on()) {
+        const double px_out = (double)n * (S / 2) * (S / 2);
+        prof = sq_prof_begin("conv1_pool_bf16", 2.0 * px_out * 64 * 147, (double)n * S * S * 3 + (double)n * (S / 4) * (S / 4) * 64 * 2, stream);
+    }
+    hipLaunchKernelGGL(conv1_pool_kernel, dim3(grid), dim3(256), lds, stream, a);
+    SQ_LAUNCH_CHECK();
+    if (prof >= 0) sq_prof_end(prof, stream);
+    return SQ_OK;
+}

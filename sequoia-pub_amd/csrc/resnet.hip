@@ -9,11 +9,14 @@
 // the host in fp64).  Every convolution is one launch of the NT GEMM engine:
 //   1x1 stride 1        plain GEMM on [n*H*W, Cin]
 //   3x3 / 1x1 stride 2  implicit GEMM (the A-tile loader gathers the taps, zero padding via buffer OOB)
-//   conv1 7x7 (Cin = 3) explicit im2col (K = 147 padded to 152) fused with the uint8 -> normalised cast
-// with bias + residual + ReLU in the GEMM epilogue.  Max-pool and the final 7x7 average are small
-// memory-bound kernels.
+//   conv1 7x7 (Cin = 3) fp32: explicit im2col (K = 147 padded to 152) fused with the uint8 -> normalised cast,
+//                       then the max-pool kernel;  bf16: one fused stem kernel (conv1.hip)
+// with bias + residual + ReLU in the GEMM epilogue.  The final 7x7 average is a small memory-bound kernel.
 #include "../../include/sequoia_hip.h"
 #include "gemm.h"
+
+int sq_launch_conv1_pool_bf16(const uint8_t* u8, const float* f32_nchw, const bf16_t* w152, const float* bias, bf16_t* out,
+                              int n, int S, hipStream_t stream);
 
 namespace {
 
@@ -163,7 +166,7 @@ void rn_bufs(int dtype, int n, int S, char* base, RnBufs* o) {
     auto take = [&](size_t bytes) { off = sq_align_up(off, 256); char* p = base ? base + off : nullptr; off += bytes; return (void*)p; };
     const size_t es = sq_dtype_size(dtype);
     const size_t OH = S / 2;
-    o->col = take((size_t)n * OH * OH * CONV1_KP * es);
+    o->col = dtype == SQ_BF16 ? nullptr : take((size_t)n * OH * OH * CONV1_KP * es);    // bf16: fused stem, no im2col matrix
     const size_t act = (size_t)n * OH * OH * 64 * es;          // largest activation: conv1 out == layer1 out
     for (int i = 0; i < 5; ++i) o->act[i] = take(act);
     o->bytes = sq_align_up(off, 256);
@@ -219,8 +222,8 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
     auto W = [&](const sq_conv_desc& d) { return (const void*)((const char*)weights + (size_t)d.w_off * es); };
     const size_t w_bytes_total = (size_t)lay.w_total * es;
     const size_t act_cap = (size_t)n * (S / 2) * (S / 2) * 64 * es;
-    SQ_REQUIRE(act_cap < (1ull << 31) && (size_t)n * (S / 2) * (S / 2) * CONV1_KP * es < (1ull << 31),
-               "resnet50: sub-batch of %d patches exceeds the 2 GiB buffer-descriptor limit; use <= 256", n);
+    SQ_REQUIRE(act_cap < (1ull << 31) && (lp || (size_t)n * (S / 2) * (S / 2) * CONV1_KP * es < (1ull << 31)),
+               "resnet50: sub-batch of %d patches exceeds the 2 GiB buffer-descriptor limit (bf16: <= 1300 patches of 224, fp32: <= 280)", n);
 
     // conv as a GEMM launch.  in: NHWC [n, H, H, cin];  out: [n, OH, OH, cout]
     auto conv = [&](const sq_conv_desc& d, const void* in, int H, void* out, int OH, const void* res, int act) -> int {
@@ -243,28 +246,31 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
 #define RUN(expr) do { if (int _e = (expr)) return _e; } while (0)
 
     const int OH1 = S / 2;
-    {   // conv1 + bn1 + relu
-        const size_t work = (size_t)n * OH1 * OH1 * (CONV1_KP / 8);
-        size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
-        if (lp) hipLaunchKernelGGL(im2col_conv1_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (bf16_t*)b.col, n, S, OH1);
-        else hipLaunchKernelGGL(im2col_conv1_kernel<float>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (float*)b.col, n, S, OH1);
-        SQ_LAUNCH_CHECK();
-        GemmArgs g;
-        const sq_conv_desc& d = lay.conv[0];
-        g.M = n * OH1 * OH1; g.N = 64; g.K = CONV1_KP;
-        g.A = b.col; g.lda = CONV1_KP; g.a_bytes = (size_t)g.M * CONV1_KP * es;
-        g.B = W(d); g.ldb = CONV1_KP; g.b_bytes = w_bytes_total;
-        g.bias = bias + d.b_off; g.act = SQ_ACT_RELU;
-        g.C = b.act[0]; g.ldc = 64; g.out_dtype = dtype;
-        RUN(sq_launch_gemm(g, dtype, st));
-    }
     int H = OH1 / 2;    // after the max-pool
-    {
-        const size_t work = (size_t)n * H * H * 64 / (16 / es);
-        size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
-        if (lp) hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3((int)nb), dim3(256), 0, st, (const bf16_t*)b.act[0], (bf16_t*)b.act[1], n, OH1, H, 64);
-        else hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3((int)nb), dim3(256), 0, st, (const float*)b.act[0], (float*)b.act[1], n, OH1, H, 64);
-        SQ_LAUNCH_CHECK();
+    if (lp) {           // conv1 + bn1 + relu + maxpool in one kernel (conv1.hip)
+        const sq_conv_desc& d = lay.conv[0];
+        RUN(sq_launch_conv1_pool_bf16(patches_u8, patches_f32_nchw, (const bf16_t*)W(d), bias + d.b_off, (bf16_t*)b.act[1], n, S, st));
+    } else {
+        {   // conv1 + bn1 + relu
+            const size_t work = (size_t)n * OH1 * OH1 * (CONV1_KP / 8);
+            size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
+            hipLaunchKernelGGL(im2col_conv1_kernel<float>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (float*)b.col, n, S, OH1);
+            SQ_LAUNCH_CHECK();
+            GemmArgs g;
+            const sq_conv_desc& d = lay.conv[0];
+            g.M = n * OH1 * OH1; g.N = 64; g.K = CONV1_KP;
+            g.A = b.col; g.lda = CONV1_KP; g.a_bytes = (size_t)g.M * CONV1_KP * es;
+            g.B = W(d); g.ldb = CONV1_KP; g.b_bytes = w_bytes_total;
+            g.bias = bias + d.b_off; g.act = SQ_ACT_RELU;
+            g.C = b.act[0]; g.ldc = 64; g.out_dtype = dtype;
+            RUN(sq_launch_gemm(g, dtype, st));
+        }
+        {
+            const size_t work = (size_t)n * H * H * 64 / (16 / es);
+            size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
+            hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3((int)nb), dim3(256), 0, st, (const float*)b.act[0], (float*)b.act[1], n, OH1, H, 64);
+            SQ_LAUNCH_CHECK();
+        }
     }
     // bottleneck stack: x lives in act[xi]; t1, t2, ds, y are the other four buffers
     int xi = 1, ci = 1;
