@@ -37,7 +37,7 @@ struct Conv1Args {
     int n, S, tiles_per_side, tiles;
 };
 
-__global__ __launch_bounds__(256) void conv1_pool_kernel(const Conv1Args p) {
+__global__ __launch_bounds__(256, 2) void conv1_pool_kernel(const Conv1Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_in = smem;
     char* s_out = smem + IN_BYTES;
@@ -83,31 +83,67 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(const Conv1Args p) {
     }
 
     const int S = p.S, OH = S / 2, PH = S / 4;
-    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
-        const int img = tile / (p.tiles_per_side * p.tiles_per_side);
-        const int tt = tile - img * p.tiles_per_side * p.tiles_per_side;
-        const int ty = tt / p.tiles_per_side, tx = tt - ty * p.tiles_per_side;
-        const int iy0 = 4 * TP * ty - 5, ix0 = 4 * TP * tx - 5;     // input pixel of staged (0, 0)
+    const int tps2 = p.tiles_per_side * p.tiles_per_side;
+    constexpr int NPX = (RH * RW + 255) / 256;     // staged pixels per thread (7)
 
-        // ---- stage the normalised input window
-        for (int idx = tid; idx < RH * RW; idx += 256) {
+    // uint8 source: the NEXT tile's pixels are fetched into registers while this tile is on the MFMA
+    uint8_t pre[NPX][3];
+    uint32_t pre_ok = 0;
+    auto prefetch = [&](int tile) {
+        const int img = tile / tps2, tt = tile - img * tps2;
+        const int ty = tt / p.tiles_per_side, tx = tt - ty * p.tiles_per_side;
+        const int iy0 = 4 * TP * ty - 5, ix0 = 4 * TP * tx - 5;
+        const uint8_t* base = p.u8 + (size_t)img * S * S * 3;
+        pre_ok = 0;
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int idx = tid + j * 256;
             const int r = idx / RW, q = idx - r * RW;
             const int iy = iy0 + r, ix = ix0 + q;
-            uint32_t lo = 0, hi = 0;
-            if ((unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S) {
-                if (p.u8) {
-                    const uint8_t* px = p.u8 + (((size_t)img * S + iy) * S + ix) * 3;
-                    lo = (uint32_t)s_lut[px[0]] | ((uint32_t)s_lut[256 + px[1]] << 16);
-                    hi = (uint32_t)s_lut[512 + px[2]];
-                } else {
+            const bool ok = idx < RH * RW && (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
+            const uint8_t* px = base + ((uint32_t)(ok ? iy : 0) * S + (ok ? ix : 0)) * 3;
+            pre[j][0] = px[0]; pre[j][1] = px[1]; pre[j][2] = px[2];
+            pre_ok |= ok ? (1u << j) : 0u;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < RH * RW) {
+                const bool ok = (pre_ok >> j) & 1;
+                const uint32_t lo = ok ? ((uint32_t)s_lut[pre[j][0]] | ((uint32_t)s_lut[256 + pre[j][1]] << 16)) : 0u;
+                const uint32_t hi = ok ? (uint32_t)s_lut[512 + pre[j][2]] : 0u;
+                *reinterpret_cast<u32x2*>(s_in + idx * 8) = u32x2{lo, hi};
+            }
+        }
+    };
+    if (p.u8 && (int)blockIdx.x < p.tiles) prefetch(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const int img = tile / tps2;
+        const int tt = tile - img * tps2;
+        const int ty = tt / p.tiles_per_side, tx = tt - ty * p.tiles_per_side;
+
+        // ---- stage the normalised input window
+        if (p.u8) {
+            commit();
+        } else {
+            const int iy0 = 4 * TP * ty - 5, ix0 = 4 * TP * tx - 5;     // input pixel of staged (0, 0)
+            for (int idx = tid; idx < RH * RW; idx += 256) {
+                const int r = idx / RW, q = idx - r * RW;
+                const int iy = iy0 + r, ix = ix0 + q;
+                uint32_t lo = 0, hi = 0;
+                if ((unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S) {
                     const float* px = p.f32 + ((size_t)img * 3 * S + iy) * S + ix;
                     lo = pack_bf16x2(px[0], px[(size_t)S * S]);
                     hi = (uint32_t)f32_to_bf16(px[2 * (size_t)S * S]);
                 }
+                *reinterpret_cast<u32x2*>(s_in + idx * 8) = u32x2{lo, hi};
             }
-            *reinterpret_cast<u32x2*>(s_in + idx * 8) = u32x2{lo, hi};
         }
         __syncthreads();
+        if (p.u8 && tile + (int)gridDim.x < p.tiles) prefetch(tile + gridDim.x);
 
         // ---- 17 x 17 x 64 conv tile on the MFMA
         f32x16 acc[5];
