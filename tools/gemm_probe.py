@@ -45,6 +45,12 @@ def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6)):
 
 
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "resnet":
+        for M, N, K in [(39200, 1024, 256), (9800, 2048, 512), (39200, 256, 1024), (156800, 512, 128), (156800, 128, 512),
+                        (9800, 512, 2048), (627200, 64, 256), (627200, 256, 64), (39200, 512, 1024)]:
+            probe(M, N, K, _lib.SQ_BF16, tiles=(0, 22, 21, 12, 11), dbgs=(0,))
+        sys.exit(0)
     probe(6400, 1024, 1024, _lib.SQ_BF16, tiles=(22,), dbgs=(0, 1))
     probe(6400, 1024, 1024, _lib.SQ_F32, tiles=(22,), dbgs=(0,))
     probe(8192, 8192, 8192, _lib.SQ_BF16, tiles=(22,), dbgs=(0,))
