@@ -457,7 +457,14 @@ template <typename T, int WTM, int WTN>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    const size_t lds = 2 * (BM + BN) * 128;
+    // two operand buffers, or -- when K fits one tile -- just one (never smaller than the fp32 epilogue stage):
+    // short-K products are memory-bound and want as many blocks per CU as fit
+    const int nk1 = (a.K + (int)(128 / sizeof(T)) - 1) / (int)(128 / sizeof(T));
+    size_t lds = 2 * (BM + BN) * 128;
+    if (nk1 == 1 && a.splitk == 1) {
+        lds = (BM + BN) * 128;
+        if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;
+    }
     const dim3 grid(tiles, a.splitk, a.batch);
     if (int e = a.conv ? launch_epi<T, WTM, WTN, true>(a, grid, lds, stream) : launch_epi<T, WTM, WTN, false>(a, grid, lds, stream)) return e;
     if (a.splitk > 1) return launch_reduce(a, stream);
