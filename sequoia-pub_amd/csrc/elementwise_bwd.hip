@@ -6,7 +6,7 @@ namespace {
 
 constexpr float LN_EPS = 1e-5f;
 constexpr int COLSUM_SPLITS = 64;
-constexpr int LN_BWD_PARTIALS = 1024;
+constexpr int LN_BWD_PARTIALS = 512;     // partial [dg | db] rows a backward kernel leaves: one colsum_small launch finishes them
 
 template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p, size_t i);
 template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p, size_t i) { return p[i]; }
@@ -42,6 +42,30 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
     __syncthreads();
     if (ty == 0 && c < C) {
         const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (out2 && c >= split) out2[c - split] = v;
+        else out[c] = v;
+    }
+}
+
+// few rows (<= 512 partial rows of a backward kernel): ONE launch; block = 16 columns x 16 row lanes, the 16 lane
+// sums combined through LDS in a fixed tree (deterministic); columns >= split go to out2
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ x, int R, int C, int ld, float* __restrict__ out,
+                                                           float* __restrict__ out2, int split) {
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int r = ty;
+        for (; r + 16 < R; r += 32) { a0 += x[(size_t)r * ld + c]; a1 += x[(size_t)(r + 16) * ld + c]; }
+        if (r < R) a0 += x[(size_t)r * ld + c];
+    }
+    red[ty][tx] = a0 + a1;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) v += (red[k][tx] + red[k + 1][tx]) + (red[k + 2][tx] + red[k + 3][tx]);
         if (out2 && c >= split) out2[c - split] = v;
         else out[c] = v;
     }
@@ -109,7 +133,7 @@ __global__ void batch_sum_kernel(const float* __restrict__ x, float* __restrict_
     out[i] = acc;
 }
 
-// one wave per row (grid-strided); lane owns float4 columns i*64+lane; per-wave dg/db partials go to ws
+// one wave per row (grid-strided); lane owns float4 columns i*64+lane; per-block dg/db partials go to ws
 template <int MAXI>
 __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ g, const float* __restrict__ dres,
@@ -181,12 +205,27 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
             }
         }
     }
-    float4* wg = reinterpret_cast<float4*>(ws + (size_t)wave_global * 2 * D);
-    float4* wb = reinterpret_cast<float4*>(ws + (size_t)wave_global * 2 * D + D);
+    // one partial row [dg | db] per BLOCK: waves 1..3 hand their sums to wave 0 through LDS, added in wave order
+    __shared__ float4 red[3][2][64];
+    const int wave = threadIdx.x >> 6;
+    float4* wg = reinterpret_cast<float4*>(ws + (size_t)blockIdx.x * 2 * D);
+    float4* wb = reinterpret_cast<float4*>(ws + (size_t)blockIdx.x * 2 * D + D);
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
+        if (wave > 0) { red[wave - 1][0][lane] = ag[i]; red[wave - 1][1][lane] = ab[i]; }
+        __syncthreads();
         const int c = i * 64 + lane;
-        if (c < D4) { wg[c] = ag[i]; wb[c] = ab[i]; }
+        if (wave == 0 && c < D4) {
+            float4 a = ag[i], b = ab[i];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const float4 ra = red[w][0][lane], rb = red[w][1][lane];
+                a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w;
+                b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
+            }
+            wg[c] = a; wb[c] = b;
+        }
+        __syncthreads();
     }
 }
 
@@ -250,6 +289,11 @@ __global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const float* __restr
 
 int colsum_impl(const void* x, int dtype, int R, int C, int ld, float* ws, float* out, hipStream_t s, float* out2 = nullptr,
                 int split = 0) {
+    if (dtype == SQ_F32 && R <= 512) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)x, R, C, ld, out, out2, split);
+        SQ_LAUNCH_CHECK();
+        return SQ_OK;
+    }
     int nsplit = (R + 63) / 64;
     if (nsplit > COLSUM_SPLITS) nsplit = COLSUM_SPLITS;
     if (nsplit < 1) nsplit = 1;
@@ -310,7 +354,7 @@ int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const floa
                      float* db, float* ws, int R, int D, hipStream_t s) {
     SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows_bwd: D=%d", D);
     int nblk = (R + 3) / 4;
-    if (nblk > LN_BWD_PARTIALS / 4) nblk = LN_BWD_PARTIALS / 4;
+    if (nblk > LN_BWD_PARTIALS) nblk = LN_BWD_PARTIALS;
     const dim3 grid(nblk), block(256);
     if (D <= 1024) hipLaunchKernelGGL(ln_rows_bwd_kernel<4>, grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);
     else if (D <= 2048) hipLaunchKernelGGL(ln_rows_bwd_kernel<8>, grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);
@@ -318,7 +362,7 @@ int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const floa
     SQ_LAUNCH_CHECK();
     // partial rows are [dg | db] of length 2D: one column-sum over nblk*4 partial rows, then split
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * D;
-    return colsum_impl(ws, SQ_F32, nblk * 4, 2 * D, 2 * D, cs_ws, dg, s, db, D);
+    return colsum_impl(ws, SQ_F32, nblk, 2 * D, 2 * D, cs_ws, dg, s, db, D);
 }
 
 int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const float* b, void* dx, int out_dtype, float* dg,
