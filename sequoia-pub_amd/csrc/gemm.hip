@@ -472,6 +472,9 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 }
 
 int g_force_tile = 0, g_dbg = 0, g_force_split = 0;
+}
+extern int g_tn_force_split;
+namespace {
 
 template <typename T>
 int launch_t(const GemmArgs& a_in, hipStream_t stream) {
@@ -517,6 +520,7 @@ extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
     else if (key == 2) g_force_split = value;
+    else if (key == 4) g_tn_force_split = value;
     else return SQ_ERR_ARG;
     return SQ_OK;
 }

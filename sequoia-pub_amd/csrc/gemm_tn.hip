@@ -61,8 +61,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
     const bool cs_block = (int)blockIdx.x < cs_blocks;
     if (cs_block && (int)blockIdx.x >= tiles_m) return;
     const int bx = (int)blockIdx.x - cs_blocks;
-    const int m0 = (cs_block ? (int)blockIdx.x : bx / tiles_n) * BT;
-    const int n0 = cs_block ? 0 : (bx % tiles_n) * BT;
+    // tile -> XCD: blocks go round-robin over the 8 XCDs (each with its own L2).  Both operands are long (K rows),
+    // so an XCD should own a compact 4 x 2 patch of tiles (it then reads 4 A strips + 2 B strips per 8 tiles) rather
+    // than a whole row or column of the tile grid (1 + 8 strips).  Bijective when the patches divide evenly.
+    int mt = bx / tiles_n, nt = bx % tiles_n;
+    if ((tiles_m & 3) == 0 && (tiles_n & 1) == 0 && (((tiles_m >> 2) * (tiles_n >> 1)) & 7) == 0) {
+        const int q = bx & 7, i = bx >> 3;
+        const int patch = q + 8 * (i >> 3), j = i & 7;
+        const int pn = tiles_n >> 1;
+        mt = (patch / pn) * 4 + (j >> 1);
+        nt = (patch % pn) * 2 + (j & 1);
+    }
+    const int m0 = (cs_block ? (int)blockIdx.x : mt) * BT;
+    const int n0 = cs_block ? 0 : nt * BT;
     const int z = blockIdx.z;
 
     const T* Ab = reinterpret_cast<const T*>(p.A) + (long long)z * p.sA;
@@ -275,6 +286,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
 
 }  // namespace
 
+int g_tn_force_split = 0;      // experiment knob (sq_dbg_set key 4)
+
 int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
     GemmArgs a = a_in;
     const int epc = dtype == SQ_BF16 ? 8 : 4;
@@ -311,6 +324,7 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
         while (s > 1 && (size_t)s * ((size_t)a.M * a.N * a.batch + (a.colsum_a ? a.M : 0)) * sizeof(float) > a.splitk_ws_bytes) --s;
         if (s > 1) a.splitk = (int)s;
     }
+    if (g_tn_force_split > 0 && a.splitk_ws && (size_t)g_tn_force_split * ((size_t)a.M * a.N * a.batch + a.M) * 4 <= a.splitk_ws_bytes) a.splitk = g_tn_force_split;
     int prof = -1;
     if (sq_prof_on()) {
         const double es = dtype == SQ_BF16 ? 2.0 : 4.0;

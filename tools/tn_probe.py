@@ -1,0 +1,36 @@
+"""Weight-gradient (TN) GEMM timing vs K-slice count: python tools/tn_probe.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sequoia_pub_amd import _lib
+
+
+def run(T, NO, NI, splits, bias=True):
+    lib = _lib.lib()
+    dY = torch.randn(T, NO, device="cuda").bfloat16()
+    X = torch.randn(T, NI, device="cuda").bfloat16()
+    dW = torch.empty(NO, NI, device="cuda")
+    db = torch.empty(NO, device="cuda") if bias else None
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for sp in splits:
+        lib.sq_dbg_set(4, sp)
+        def call():
+            _lib.check(lib.sq_linear_weight_grad(_lib.SQ_BF16, _lib.ptr(dY), NO, _lib.ptr(X), NI, _lib.ptr(dW), NI, _lib.ptr(db), NO, NI, T,
+                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        for _ in range(5):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 50 * 1e3
+        print(f"T={T} {NO}x{NI} split {sp:2d}: {us:7.1f} us  {2.0 * T * NO * NI / us / 1e6:7.1f} TF (kernel + reduce)")
+    lib.sq_dbg_set(4, 0)
+
+
+if __name__ == "__main__":
+    run(6400, 1024, 1024, (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14))
+    run(6400, 1024, 1024, (0, 4, 7), bias=False)
