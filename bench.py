@@ -65,7 +65,7 @@ def timed_region(step_fn, steps, warmup, world, device):
     return dt
 
 
-def roofline_from_profile(step_fn, steps, dtype_name):
+def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
     """Run `steps` more steps with HIP-event instrumentation on and pick the dominant kernel."""
     _lib.prof_enable(True)
     for _ in range(steps):
@@ -89,7 +89,16 @@ def roofline_from_profile(step_fn, steps, dtype_name):
                 "frac": round(ach / HBM_PEAK_GBS, 4)}
     roof.update({"traffic": None, "kernel": dom["name"], "avg_us": round(avg_s * 1e6, 2),
                  "launches_per_step": dom["count"] // max(steps, 1),
-                 "share_of_instrumented_time": round(dom["total_ms"] / total_ms, 3)})
+                 "share_of_instrumented_time": round(dom["total_ms"] / total_ms, 3),
+                 "algorithmic_bytes": round(dom["bytes"]), "algorithmic_flops": round(dom["flops"])})
+    # HBM-side bytes per launch of this kernel/shape from the committed rocprofv3 PMC passes of the same command
+    # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py)
+    pmc = os.path.join(ROOT, "profiles", f"r01_{workload_name}_{dtype_name}_pmc.json")
+    if os.path.exists(pmc):
+        cls = json.load(open(pmc)).get("classes", {}).get(dom["name"])
+        if cls and "hbm_bytes_avg" in cls:
+            roof["traffic"] = cls["hbm_bytes_avg"]
+            roof["traffic_source"] = os.path.relpath(pmc, ROOT)
     return roof, recs
 
 
@@ -272,7 +281,7 @@ def main():
     slides = wl["slides_per_step"] * world * args.steps
     value = slides / dt
 
-    roof, recs = roofline_from_profile(wl["step"], min(args.steps, 5), args.dtype)
+    roof, recs = roofline_from_profile(wl["step"], min(args.steps, 5), args.dtype, args.workload)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = wl["cpu_baseline"]()

@@ -87,7 +87,7 @@ extern "C" int sq_prof_report(char* buf, size_t cap) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             Agg& a = agg[r.name];
-            a.count++; a.ms += ms; a.flops = r.flops; a.bytes = r.bytes;
+            a.count++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;      // summed; reported as the per-launch mean
         }
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
@@ -98,7 +98,8 @@ extern "C" int sq_prof_report(char* buf, size_t cap) {
     for (auto& kv : agg) {
         char line[384];
         snprintf(line, sizeof(line), "%s{\"name\":\"%s\",\"count\":%ld,\"total_ms\":%.6f,\"flops\":%.1f,\"bytes\":%.1f}",
-                 first ? "" : ",", kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.flops, kv.second.bytes);
+                 first ? "" : ",", kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.flops / kv.second.count,
+                 kv.second.bytes / kv.second.count);
         s += line;
         first = false;
     }

@@ -560,8 +560,13 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
         const double es = dtype == SQ_BF16 ? 2.0 : 4.0;
         const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
         const double a_elems = a.conv ? (double)a.M / (a.OH * a.OW) * a.H * a.W * a.Cin : (double)a.M * a.K;
-        const double bytes = (a_elems * es + (double)a.N * a.K * es) * a.batch +
-                             (double)a.M * a.N * a.batch * (a.out_dtype == SQ_BF16 ? 2.0 : 4.0);
+        // every operand read once, every output written once (residual / GELU' source / extra copies included)
+        double mn_bytes = a.out_dtype == SQ_BF16 ? 2.0 : 4.0;
+        if (a.res) mn_bytes += a.res_dtype == SQ_BF16 ? 2.0 : 4.0;
+        if (a.gelu_grad_of) mn_bytes += 4.0;
+        if (a.Cpre) mn_bytes += 4.0;
+        if (a.C2) mn_bytes += 2.0;
+        const double bytes = (a_elems * es + (double)a.N * a.K * es) * a.batch + (double)a.M * a.N * a.batch * mn_bytes;
         char name[96];
         snprintf(name, sizeof(name), "%s_%s_M%d_N%d_K%d_b%d", a.conv ? "conv" : "gemm", dtype == SQ_BF16 ? "bf16" : "f32",
                  a.M, a.N, a.K, a.batch);

@@ -15,11 +15,12 @@ import re
 import sys
 
 
-def load(d):
+def load(d, by_grid=False):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            key = r["Kernel_Name"] + ("|grid=" + r["Grid_Size"] if by_grid else "")
+            out[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
 
@@ -28,27 +29,53 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
+def row_of(cs):
+    row = {"dispatches": max(n for _, n in cs.values())}
+    if "FETCH_SIZE" in cs:
+        row["fetch_bytes_avg"] = round(cs["FETCH_SIZE"][0] * 1024 * 2)
+    if "WRITE_SIZE" in cs:
+        row["write_bytes_avg"] = round(cs["WRITE_SIZE"][0] * 1024)
+    if "fetch_bytes_avg" in row and "write_bytes_avg" in row:
+        row["hbm_bytes_avg"] = row["fetch_bytes_avg"] + row["write_bytes_avg"]
+    for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES"):
+        if c in cs:
+            row[c] = round(cs[c][0])
+    return row
+
+
 def main():
-    tag, out_path, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    """extra args NAME=SUBSTRING:GRID name a bench kernel class: dispatches whose symbol contains SUBSTRING and
+    whose total grid size (threads) is GRID, i.e. one problem shape."""
+    args = sys.argv[1:]
+    classes = [a for a in args if "=" in a and ":" in a.split("=", 1)[1] and not a.startswith("/")]
+    args = [a for a in args if a not in classes]
+    tag, out_path, dirs = args[0], args[1], args[2:]
     merged = collections.defaultdict(dict)
     for d in dirs:
         for k, cs in load(d).items():
             for c, v in cs.items():
                 merged[short(k)][c] = (sum(v) / len(v), len(v))
-    rows = {}
-    for k, cs in merged.items():
-        row = {"dispatches": max(n for _, n in cs.values())}
-        if "FETCH_SIZE" in cs:
-            row["fetch_bytes_avg"] = round(cs["FETCH_SIZE"][0] * 1024 * 2)
-        if "WRITE_SIZE" in cs:
-            row["write_bytes_avg"] = round(cs["WRITE_SIZE"][0] * 1024)
-        if "fetch_bytes_avg" in row and "write_bytes_avg" in row:
-            row["hbm_bytes_avg"] = row["fetch_bytes_avg"] + row["write_bytes_avg"]
-        for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES"):
-            if c in cs:
-                row[c] = round(cs[c][0])
-        rows[k] = row
-    json.dump({"tag": tag, "note": "FETCH_SIZE x 1024 x 2 (gfx950 correction), WRITE_SIZE x 1024; averages per dispatch",
+    rows = {k: row_of(cs) for k, cs in merged.items()}
+    cls_out = {}
+    if classes:
+        bygrid = collections.defaultdict(dict)
+        for d in dirs:
+            for k, cs in load(d, True).items():
+                for c, v in cs.items():
+                    bygrid[short(k.split("|grid=")[0]) + "|grid=" + k.split("|grid=")[1]][c] = (sum(v) / len(v), len(v))
+        for spec in classes:
+            name, rest = spec.split("=", 1)
+            sub, grid = rest.rsplit(":", 1)
+            acc = collections.defaultdict(lambda: [0.0, 0])
+            for k, cs in bygrid.items():
+                if sub in k and k.endswith("|grid=" + grid):
+                    for c, (avg, n) in cs.items():
+                        acc[c][0] += avg * n
+                        acc[c][1] += n
+            if acc:
+                cls_out[name] = row_of({c: (t / n, n) for c, (t, n) in acc.items()})
+                cls_out[name]["match"] = spec
+    json.dump({"tag": tag, "classes": cls_out, "note": "FETCH_SIZE x 1024 x 2 (gfx950 correction), WRITE_SIZE x 1024; averages per dispatch",
                "kernels": dict(sorted(rows.items(), key=lambda kv: -kv[1].get("hbm_bytes_avg", 0) * kv[1]["dispatches"]))},
               open(out_path, "w"), indent=1)
     print("wrote", out_path, len(rows), "kernels")
