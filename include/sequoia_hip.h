@@ -160,6 +160,16 @@ int sq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
 int sq_batch_metrics(const float* pred, const float* target, int batch, int num_outputs, float* out3, void* scratch,
                      sq_stream_t stream);
 
+/* Per-gene test-set statistics of evaluation/evaluate_model.py:67-96 for real / pred / random [n, G] (row-major,
+ * n = test slides <= 8192).  out9 is double [9][G]: 0 r(real, pred), 1 r(real, random), 2 r(pred, random)
+ * (scipy.stats.pearsonr: centred, clipped to [-1, 1]; NaN when a column is constant), 3 RMSE(real, pred),
+ * 4 RMSE(real, random), 5 mean(real), 6 / 7 the 0.25 / 0.75 quantiles of real (numpy linear method),
+ * 8 = 1.0 when any of the three columns is constant (the reference's len(set(col)) == 1 branch).
+ * The p-values (Student t, Steiger) are O(G) host arithmetic on these. */
+size_t sq_gene_eval_workspace_bytes(int n, int num_outputs);
+int sq_gene_eval_stats(const float* real, const float* pred, const float* random_pred, int n, int num_outputs, double* out9,
+                       void* workspace, size_t workspace_bytes, sq_stream_t stream);
+
 /* ------------------------------------------------------------------------------
  * Per-slide k-Means + cluster means  (pre_processing/kmean_features.py:96-108:
  *   KMeans(n_clusters=100, random_state=0).fit(features).labels_ ; per-label np.mean(...))

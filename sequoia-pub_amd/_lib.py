@@ -89,6 +89,10 @@ def _declare(lib):
     lib.sq_vis_backward_workspace_bytes.argtypes = [ctypes.POINTER(VisConfig), i32, i32]
     lib.sq_vis_backward.restype = i32
     lib.sq_vis_backward.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, vp, i32, vp, sz, vp, sz, vp]
+    lib.sq_gene_eval_workspace_bytes.restype = sz
+    lib.sq_gene_eval_workspace_bytes.argtypes = [i32, i32]
+    lib.sq_gene_eval_stats.restype = i32
+    lib.sq_gene_eval_stats.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.sq_vis_backward_buckets.restype = i32
     lib.sq_vis_backward_buckets.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, vp, i32, vp, sz, vp, sz, vp,
                                             ctypes.POINTER(vp), i32]

@@ -253,8 +253,53 @@ def gold_metrics_and_train():
     print("metrics: corr", corr, "epoch losses", tr)
 
 
+def gold_evalstats():
+    """evaluate_model.py:57-125 executed with the reference's own CorrelationStats.dependent_corr, scipy's pearsonr
+    and numpy's quantile on float32 columns, as the script would on DataFrame columns.  (The script itself cannot
+    run here: sklearn 1.7 removed mean_squared_error(squared=False); statsmodels/seaborn are absent.  The RMSE is
+    the same quantity, sqrt(mean((a-b)^2)); fdrcorrection is restated in the oracle.)"""
+    from scipy import stats
+    from evaluation.CorrelationStats import dependent_corr
+    rs = np.random.RandomState(17)
+    n, G = 137, 60
+    real = (rs.rand(n, G) * 6).astype(np.float32)
+    pred = (0.6 * real + rs.randn(n, G) * 1.2 + 1).astype(np.float32)
+    rnd = (rs.rand(n, G) * 6).astype(np.float32)
+    pred[:, 4] = 2.5                       # constant prediction
+    real[:, 11] = 0.0                      # constant (unexpressed) gene
+    rnd[:, 20] = 1.0                       # constant random-model output
+    pred[:, 30] = real[:, 30]              # perfect prediction (r clipped to 1, rmse 0)
+    keys = ("pred_real_r", "random_real_r", "pearson_p", "Steiger_p", "rmse_pred", "rmse_random", "rmse_quantile_norm", "rmse_mean_norm")
+    out = {k: np.zeros(G) for k in keys}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for g in range(G):
+            r, p, z = real[:, g], pred[:, g], rnd[:, g]
+            if len(set(p)) == 1 or len(set(r)) == 1 or len(set(z)) == 1:
+                xy, xz, yz = 0, 0, 0
+                p1, pp = 1, 1
+            else:
+                xy, p1 = stats.pearsonr(r, p)
+                xz, p2 = stats.pearsonr(r, z)
+                yz, p3 = stats.pearsonr(p, z)
+                t, pp = dependent_corr(xy, xz, yz, len(r), twotailed=False, conf_level=0.95, method='steiger')
+            rmse_p = float(np.sqrt(np.mean((r - p) ** 2)))
+            rmse_r = float(np.sqrt(np.mean((r - z) ** 2)))
+            out["pred_real_r"][g] = xy
+            out["random_real_r"][g] = xz
+            out["pearson_p"][g] = p1
+            out["Steiger_p"][g] = pp
+            out["rmse_pred"][g] = rmse_p
+            out["rmse_random"][g] = rmse_r
+            out["rmse_quantile_norm"][g] = rmse_p / (np.quantile(r, 0.75) - np.quantile(r, 0.25) + 1e-5)
+            out["rmse_mean_norm"][g] = rmse_p / np.mean(r)
+    np.savez_compressed(os.path.join(HERE, "evalstats.npz"), real=real, pred=pred, random=rnd,
+                        scipy_version=np.array(__import__("scipy").__version__), **out)
+    print("evalstats: mean r", np.nanmean(out["pred_real_r"]), "steiger p[0:3]", out["Steiger_p"][:3])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics"]
+    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats"]
     if "vit_tiny" in which:
         gold_vit_tiny()
     if "vis_tiny" in which:
@@ -267,3 +312,5 @@ if __name__ == "__main__":
         gold_kmeans()
     if "metrics" in which:
         gold_metrics_and_train()
+    if "evalstats" in which:
+        gold_evalstats()
