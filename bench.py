@@ -249,7 +249,44 @@ def workload_pipeline(args, rank, world, device):
                         "parallelism": f"slide-sharded x{world}"})
 
 
-WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train, "pipeline": workload_pipeline}
+def workload_spatial(args, rank, world, device):
+    """BASELINE config 5: one slide of 50 000 tiles on a 250 x 200 grid, 10 x 10 windows at stride 1 (no k-Means),
+    ViS forward per window, per-tile mean of the 20 820-gene predictions."""
+    from sequoia_pub_amd.spatial import enumerate_windows, sliding_window_all_genes
+    from sequoia_pub_amd.vis import ViS
+    torch.manual_seed(99)
+    nx, ny = args.grid
+    xs, ys = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    xtf, ytf = xs.ravel(), ys.ravel()
+    vis = ViS(**VIS_CFG, num_clusters=100, device=str(device), compute_dtype=args.dtype).to(device).eval()
+    feats = torch.randn(nx * ny, VIS_CFG["input_dim"], generator=torch.Generator().manual_seed(99 + rank)).to(device)
+    n_windows = len(enumerate_windows(xtf, ytf, 1)[0])
+
+    def step():
+        out, _ = sliding_window_all_genes(xtf, ytf, feats, vis, 1, batch_windows=args.batch_windows)
+        return out
+
+    def cpu_baseline():
+        from oracle import vis_oracle
+        sd = {k: v.cpu() for k, v in vis.state_dict().items()}
+        x = torch.randn(16, 100, VIS_CFG["input_dim"])
+
+        def fwd():
+            with torch.no_grad():
+                vis_oracle.vis_forward(sd, x)
+        rate, threads, reps = timed_cpu_sample(fwd, 16, budget_s=10.0)
+        return {"value": round(rate / n_windows, 6), "unit": "slides/s", "cores": threads, "kind": "port",
+                "sample": f"oracle ViS forward on {reps} x 16 windows ({rate:.1f} windows/s) extrapolated to {n_windows} windows; "
+                          "feature cache assumed (the reference re-embeds every tile per window), voting not timed"}
+
+    return dict(step=step, slides_per_step=1, cpu_baseline=cpu_baseline,
+                config={"workload": f"spatial: {nx * ny} tiles ({nx} x {ny} grid), {n_windows} windows of 100 tokens at stride 1, "
+                                    "ViS(D=1024, depth 6, 16 heads, G=20820) forward per window + per-tile mean vote (BASELINE config 5)",
+                        "windows_per_slide": n_windows, "batch_windows": args.batch_windows,
+                        "parallelism": f"slide-sharded x{world}"})
+
+
+WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train, "pipeline": workload_pipeline, "spatial": workload_spatial}
 
 
 def main():
@@ -263,6 +300,8 @@ def main():
     ap.add_argument("--slides", type=int, default=8, help="pipeline workload: slides per GPU per step")
     ap.add_argument("--patches", type=int, default=1000, help="pipeline workload: patches per slide")
     ap.add_argument("--sub-batch", type=int, default=500, help="pipeline workload: patches per ResNet launch group")
+    ap.add_argument("--grid", type=int, nargs=2, default=[250, 200], help="spatial workload: tile grid")
+    ap.add_argument("--batch-windows", type=int, default=1024, help="spatial workload: windows per ViS forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -170,6 +170,13 @@ size_t sq_gene_eval_workspace_bytes(int n, int num_outputs);
 int sq_gene_eval_stats(const float* real, const float* pred, const float* random_pred, int n, int num_outputs, double* out9,
                        void* workspace, size_t workspace_bytes, sq_stream_t stream);
 
+/* Per-tile vote of sliding-window predictions (spatial_vis/visualize.py:86-101): win_pred f32 [n_windows, G];
+ * tile_windows int32 [n_tiles, max_votes] = the windows containing each tile in visiting order, packed, -1 padded.
+ * mode 0: out[t] = mean of the listed rows (stride < 10, :97-101); mode 1: the last listed row (stride 10: later
+ * windows overwrite, :90-92).  Tiles in no kept window get `fill`.  out f32 [n_tiles, G]. */
+int sq_window_vote(const float* win_pred, int n_windows, int num_outputs, const int32_t* tile_windows, int n_tiles,
+                   int max_votes, int mode, float fill, float* out, sq_stream_t stream);
+
 /* ------------------------------------------------------------------------------
  * Per-slide k-Means + cluster means  (pre_processing/kmean_features.py:96-108:
  *   KMeans(n_clusters=100, random_state=0).fit(features).labels_ ; per-label np.mean(...))

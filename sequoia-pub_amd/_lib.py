@@ -93,6 +93,8 @@ def _declare(lib):
     lib.sq_gene_eval_workspace_bytes.argtypes = [i32, i32]
     lib.sq_gene_eval_stats.restype = i32
     lib.sq_gene_eval_stats.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    lib.sq_window_vote.restype = i32
+    lib.sq_window_vote.argtypes = [vp, i32, i32, vp, i32, i32, i32, ctypes.c_float, vp, vp]
     lib.sq_vis_backward_buckets.restype = i32
     lib.sq_vis_backward_buckets.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, vp, i32, vp, sz, vp, sz, vp,
                                             ctypes.POINTER(vp), i32]

@@ -10,6 +10,8 @@ reference's 2-D input quirk (the prediction depends only on the wind
 import numpy as np
 import torch
 
+from . import _lib
+
 
 def enumerate_windows(xtf, ytf, stride, size=10, min_tiles=50):
     """xtf, ytf: integer grid coordinates per tile (df order).  Returns (members [W, size*size] int64 with -1
@@ -37,45 +39,71 @@ def enumerate_windows(xtf, ytf, stride, size=10, min_tiles=50):
     return members[keep], origins[keep]
 
 
+def tile_window_lists(members, n_tiles, device):
+    """Invert members [W, 100] (window -> tiles) into int32 [n_tiles, V] (tile -> windows in visiting order, packed,
+    -1 padded); V = the largest number of windows any tile belongs to."""
+    mem = torch.as_tensor(members, device=device)
+    W, S = mem.shape
+    win = torch.arange(W, device=device).unsqueeze(1).expand(W, S)
+    valid = mem >= 0
+    tiles, wins = mem[valid], win[valid]                        # row-major: already ascending in window id per tile
+    order = torch.sort(tiles, stable=True).indices
+    tiles, wins = tiles[order], wins[order]
+    counts = torch.bincount(tiles, minlength=n_tiles)
+    V = max(int(counts.max()), 1) if tiles.numel() else 1
+    start = torch.cumsum(counts, 0) - counts
+    rank = torch.arange(tiles.numel(), device=device) - start[tiles]
+    out = torch.full((n_tiles, V), -1, dtype=torch.int32, device=device)
+    out[tiles, rank] = wins.to(torch.int32)
+    return out, counts
+
+
+@torch.no_grad()
+def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=False, batch_windows=1024):
+    """All-gene form of visualize.py:35-102 (BASELINE config 5: per-tile 20 820-gene regression): returns
+    (tile_pred f32 [n_tiles, G] with NaN for tiles no kept window covers, votes int64 [n_tiles]).
+    Window predictions stay on the device as [W, G]; the per-tile mean / last-writer rule is one sq_window_vote."""
+    _lib.require_gpu()
+    members, _ = enumerate_windows(xtf, ytf, stride)
+    dev = model.flat.device
+    feats = tile_features.to(dev, torch.float32)
+    n_tiles, D = feats.shape
+    G = model.cfg.num_outputs
+    if len(members) == 0:
+        return torch.full((n_tiles, G), float("nan"), device=dev), torch.zeros(n_tiles, dtype=torch.int64, device=dev)
+    feats_pad = torch.cat([feats, torch.zeros(1, D, device=dev)])               # index -1 -> zero row (padding)
+    mem = torch.from_numpy(members).to(dev)
+    W = mem.shape[0]
+    win_pred = torch.empty(W, G, dtype=torch.float32, device=dev)
+    for s in range(0, W, batch_windows):
+        m = mem[s:s + batch_windows]
+        x = feats_pad[m]                                                        # [w, 100, D]
+        if literal_2d:
+            # reference: model(features_all) with a 2-D [100, D] tensor, then [0]  -> depends on tile 0 only
+            x = x[:, 0:1, :].expand(-1, 100, -1).contiguous()
+        win_pred[s:s + m.shape[0]] = model(x)
+    lists, counts = tile_window_lists(mem, n_tiles, dev)
+    out = torch.empty(n_tiles, G, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().sq_window_vote(_lib.ptr(win_pred), W, G, _lib.ptr(lists), n_tiles, lists.shape[1],
+                                             1 if stride == 10 else 0, float("nan"), _lib.ptr(out), _lib.stream_ptr(dev)))
+    return out, counts
+
+
 @torch.no_grad()
 def sliding_window_method(df, tile_features, model, inds_gene_of_interest, stride, literal_2d=False, batch_windows=512):
     """visualize.py:35-102.  df: DataFrame with integer columns xcoord_tf / ycoord_tf (tile grid); tile_features:
     [n_tiles, D] tensor (row i = features of df.iloc[i], i.e. the feature cache); model: ViS on the GPU.
     Returns {gene_index: {tile_index: prediction}} exactly like the reference (stride 10: last writer wins;
     stride < 10: mean over the windows containing the tile)."""
-    members, _ = enumerate_windows(df['xcoord_tf'].values, df['ycoord_tf'].values, stride)
     genes = list(inds_gene_of_interest)
-    preds = {g: {} for g in genes}
-    if len(members) == 0:
-        return preds
-    dev = model.flat.device
-    feats = tile_features.to(dev, torch.float32)
-    D = feats.shape[1]
-    feats_pad = torch.cat([feats, torch.zeros(1, D, device=dev)])               # index -1 -> zero row (padding)
-    gidx = torch.as_tensor(genes, device=dev)
-    n_tiles = feats.shape[0]
-    acc = torch.zeros(n_tiles, len(genes), dtype=torch.float64, device=dev)
-    cnt = torch.zeros(n_tiles, dtype=torch.float64, device=dev)
-    last = torch.zeros(n_tiles, len(genes), dtype=torch.float32, device=dev)
-    mem = torch.from_numpy(members).to(dev)
-    for s in range(0, len(members), batch_windows):
-        m = mem[s:s + batch_windows]                                            # [w, 100]
-        x = feats_pad[m]                                                        # [w, 100, D] (-1 indexes the zero row)
-        if literal_2d:
-            # reference: model(features_all) with a 2-D [100, D] tensor, then [0]  -> depends on tile 0 only
-            out = model(x[:, 0:1, :].expand(-1, 100, -1).contiguous())
-        else:
-            out = model(x)
-        out = out[:, gidx]                                                      # [w, n_genes]
-        valid = m >= 0
-        rows = m[valid]
-        vals = out.unsqueeze(1).expand(-1, m.shape[1], -1)[valid]               # [n_valid, n_genes]
-        acc.index_add_(0, rows, vals.double())
-        cnt.index_add_(0, rows, torch.ones_like(rows, dtype=torch.float64))
-        last[rows] = vals            # windows are visited in the reference's (x, y) order; later batches overwrite
-    cnt_c, acc_c, last_c = cnt.cpu().numpy(), acc.cpu().numpy(), last.cpu().numpy()
+    out, counts = sliding_window_all_genes(df['xcoord_tf'].values, df['ycoord_tf'].values, tile_features, model, stride,
+                                           literal_2d=literal_2d, batch_windows=batch_windows)
+    sel = out[:, torch.as_tensor(genes, device=out.device)].cpu().numpy() if genes else np.zeros((out.shape[0], 0), np.float32)
+    cnt = counts.cpu().numpy()
     index = list(df.index)
-    for t in np.nonzero(cnt_c > 0)[0]:
+    preds = {g: {} for g in genes}
+    for t in np.nonzero(cnt > 0)[0]:
         for gi, g in enumerate(genes):
-            preds[g][index[t]] = last_c[t, gi] if stride == 10 else np.float32(acc_c[t, gi] / cnt_c[t])
+            preds[g][index[t]] = sel[t, gi]
     return preds

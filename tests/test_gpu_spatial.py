@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import vis_oracle  # noqa: E402  (checker only)
 from sequoia_pub_amd import _lib  # noqa: E402
-from sequoia_pub_amd.spatial import enumerate_windows, sliding_window_method  # noqa: E402
+from sequoia_pub_amd.spatial import enumerate_windows, sliding_window_all_genes, sliding_window_method  # noqa: E402
 from sequoia_pub_amd.vis import ViS  # noqa: E402
 
 
@@ -69,3 +69,29 @@ def test_window_enumeration_rules():
     assert (members[0] >= 0).sum() == 90 and np.all(np.diff(members[0][:90]) > 0) and np.all(members[0][90:] == -1)
     assert all(((members[i] >= 0).sum() > 50) for i in range(len(members)))
     assert origins[:, 0].max() < 11 and origins[:, 1].max() < 8          # range(0, max, stride) excludes the max itself
+
+
+@pytest.mark.parametrize("stride", [10, 2])
+def test_all_gene_vote_matches_literal_loop(stride):
+    """Config-5 form: every gene for every tile in one sq_window_vote; tiles no kept window covers are NaN."""
+    _lib.require_gpu()
+    rs = np.random.RandomState(3)
+    coords = [(x, y) for x in range(21) for y in range(23) if rs.rand() > 0.3 or x > 14]
+    df = pd.DataFrame(coords, columns=["xcoord_tf", "ycoord_tf"])
+    feats = torch.from_numpy(rs.randn(len(df), 64).astype(np.float32))
+    cfg = dict(num_outputs=37, input_dim=64, depth=1, nheads=1, dimensions_f=64, dimensions_s=64, dimensions_c=64)      # 37: scalar path
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=8), seed=9)
+    m = ViS(**cfg, device="cuda:0")
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    out, votes = sliding_window_all_genes(df["xcoord_tf"].values, df["ycoord_tf"].values, feats, m, stride, batch_windows=50)
+    out, votes = out.cpu().numpy(), votes.cpu().numpy()
+    genes = list(range(37))
+    ref = reference_loop(df, feats, sd, genes, stride, False)
+    covered = sorted(ref[0].keys())
+    assert set(np.nonzero(votes > 0)[0]) == set(covered) and 0 < len(covered)
+    assert np.isnan(out[votes == 0]).all() and not np.isnan(out[votes > 0]).any()
+    b = np.array([[ref[g][k] for g in genes] for k in covered])
+    assert rel_err(out[covered], b) < 1e-4
+    if stride < 10:
+        assert votes.max() > 10                     # tiles in the interior belong to many windows
