@@ -10,25 +10,64 @@
 #include "gemm.h"
 #include "vis.h"
 
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+
 namespace {
 
-struct BwdBufs {
-    float* dXa; void* dXa_lp;        // [M, D] running gradient (f32 + T copy)
-    float* dXb; void* dXb_lp;
+// Tensors the weight-gradient (TN) products read exist once per LAYER in bf16 mode, so those products can trail
+// the dX chain on a second stream without write-after-read hazards; fp32 mode (one stream) aliases one buffer.
+struct LayerG {
+    void* dXin_lp;                   // [M, D] T   gradient entering the layer (operand copy)
+    void* dX1_lp;                    // [M, D] T   gradient after the feed-forward block
     void* dU;                        // [M, D] T
-    float* dY;                       // [M, D] f32
     void* dP;                        // [M, HD] T
-    float* dLf;                      // [M, HD] f32
     void* dF;                        // [M, HD] T
+    void* dSm;                       // [B, HD] T
+    void* dCs_lp;                    // [B, HD] T
+};
+
+struct BwdBufs {
+    float* dXa; float* dXb;          // [M, D] f32 running gradient (ping-pong, main stream only)
+    LayerG lg[SQ_MAX_DEPTH];
+    float* dY;                       // [M, D] f32
+    float* dLf;                      // [M, HD] f32
     void* whT;                       // [D, Gp] T   transposed weights, all produced by one launch up front
     struct LayerT { void *ff2, *ff1, *proj, *wc_lf, *wc_ts, *s, *f; } wt[SQ_MAX_DEPTH];
-    float* dCs; void* dCs_lp; float* dTs; void* dSm; float* dXbar;   // [B, HD] / [B, D]
+    float* dCs; float* dTs; float* dXbar;   // [B, HD] / [B, D]
     void* dout_lp;                   // [B, Gp] T
     float* dxn; float* dxm;          // [B, D]
     float* red_ws;                   // reduction scratch
     float* skws; size_t skws_bytes;  // split-K scratch (dW products have K = tokens and few output tiles)
+    float* skws_side;                // the same for the second stream
     size_t bytes;
 };
+
+// one helper stream + event pool per device, created on first use
+struct SideStream { hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
+
+SideStream* side_stream_get(int n_events) {
+    static std::mutex mu;
+    static std::map<int, SideStream> table;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SideStream& s = table[dev];
+    if (!s.stream && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    while ((int)s.events.size() < n_events) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        s.events.push_back(e);
+    }
+    return &s;
+}
+
+bool sq_env_flag(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] && v[0] != '0';
+}
 
 void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) {
     Arena a{base, 0};
@@ -37,13 +76,26 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
     const size_t M = (size_t)B * c.num_clusters, D = c.input_dim, HD = (size_t)c.nheads * SQ_HEAD_DIM, G = c.num_outputs;
     const size_t Gp = sq_align_up(G, 8);
     const size_t W = D > HD ? D : HD;
-    o->dXa = (float*)a.take(M * D * 4); o->dXa_lp = lp ? a.take(M * D * 2) : (void*)o->dXa;
-    o->dXb = (float*)a.take(M * D * 4); o->dXb_lp = lp ? a.take(M * D * 2) : (void*)o->dXb;
-    o->dU = a.take(M * D * es);
+    o->dXa = (float*)a.take(M * D * 4);
+    o->dXb = (float*)a.take(M * D * 4);
     o->dY = (float*)a.take(M * D * 4);
-    o->dP = a.take(M * HD * es);
     o->dLf = (float*)a.take(M * HD * 4);
-    o->dF = a.take(M * HD * es);
+    o->dCs = (float*)a.take((size_t)B * HD * 4);
+    for (int l = 0; l < c.depth; ++l) {
+        LayerG& g = o->lg[l];
+        if (lp) {
+            g.dXin_lp = a.take(M * D * 2); g.dX1_lp = a.take(M * D * 2); g.dU = a.take(M * D * 2);
+            g.dP = a.take(M * HD * 2); g.dF = a.take(M * HD * 2);
+            g.dSm = a.take((size_t)B * HD * 2); g.dCs_lp = a.take((size_t)B * HD * 2);
+        } else if (l == 0) {
+            // fp32: the operand "copies" are the f32 tensors themselves (dXin / dX1 are set per layer by the caller)
+            g.dXin_lp = nullptr; g.dX1_lp = nullptr;
+            g.dU = a.take(M * D * 4); g.dP = a.take(M * HD * 4); g.dF = a.take(M * HD * 4);
+            g.dSm = a.take((size_t)B * HD * 4); g.dCs_lp = o->dCs;
+        } else {
+            g = o->lg[0];
+        }
+    }
     o->whT = a.take(D * Gp * es);
     for (int l = 0; l < c.depth; ++l) {
         o->wt[l].ff2 = a.take(D * D * es); o->wt[l].ff1 = a.take(D * D * es);
@@ -51,9 +103,7 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
         o->wt[l].wc_lf = a.take((size_t)c.nheads * 64 * 64 * es); o->wt[l].wc_ts = a.take((size_t)c.nheads * 64 * 64 * es);
         o->wt[l].s = a.take(D * HD * es); o->wt[l].f = a.take(D * HD * es);
     }
-    o->dCs = (float*)a.take((size_t)B * HD * 4); o->dCs_lp = lp ? a.take((size_t)B * HD * 2) : (void*)o->dCs;
     o->dTs = (float*)a.take((size_t)B * HD * 4);
-    o->dSm = a.take((size_t)B * HD * es);
     o->dXbar = (float*)a.take((size_t)B * D * 4);
     o->dout_lp = a.take((size_t)B * Gp * es);
     o->dxn = (float*)a.take((size_t)B * D * 4); o->dxm = (float*)a.take((size_t)B * D * 4);
@@ -63,6 +113,7 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
     o->red_ws = (float*)a.take(red * 4);
     o->skws_bytes = (size_t)16 * W * W * 4;
     o->skws = (float*)a.take(o->skws_bytes);
+    o->skws_side = lp ? (float*)a.take(o->skws_bytes) : o->skws;
     o->bytes = sq_align_up(a.off, 256);
 }
 
@@ -184,80 +235,126 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
     RUN(sq_k_ln_rows_bwd(b.dxn, w.xm, Pf(lay.head_ln_g), nullptr, b.dxm, nullptr, Gp_(lay.head_ln_g), Gp_(lay.head_ln_b),
                          b.red_ws, B, D, st));
     RUN(bucket_done(0));
-    RUN(sq_k_bcast_rows(b.dxm, 1.0f / (float)N, b.dXa, lp ? (bf16_t*)b.dXa_lp : nullptr, B, N, D, st));
+    const int top = c->depth - 1;
+    RUN(sq_k_bcast_rows(b.dxm, 1.0f / (float)N, b.dXa, lp ? (bf16_t*)b.lg[top].dXin_lp : nullptr, B, N, D, st));
 
-    float* dXcur = b.dXa; void* dXcur_lp = b.dXa_lp;
-    float* dXoth = b.dXb; void* dXoth_lp = b.dXb_lp;
+    // ---- second stream for the weight-gradient products (bf16 mode).  They are off the critical path (nothing in
+    // the dX chain reads a dW), and a GEMM of this size cannot overlap its own memory-bound epilogue with its MFMA
+    // phase (all of its blocks are resident at once and move in lock-step): a dW product running beside a dX
+    // product fills each other's idle phase.  The main stream records an event when an operand is final; the side
+    // stream waits for it.  Operands the side stream reads exist per layer (LayerG), so the dX chain never waits.
+    SideStream* side = nullptr;
+    if (lp && !sq_env_flag("SQ_BWD_ONE_STREAM")) {
+        side = side_stream_get(7 * SQ_MAX_DEPTH + 1);
+        SQ_REQUIRE(side != nullptr, "vis_backward: could not create the weight-gradient stream");
+    }
+    hipStream_t sst = side ? side->stream : st;
+    int ev_next = 0;
+    // "operand ready": later side-stream launches may read what the main stream has produced so far
+    auto ready = [&]() {
+        if (!side) return (int)SQ_OK;
+        hipEvent_t ev = side->events[ev_next++];
+        SQ_HIP_CHECK(hipEventRecord(ev, st));
+        SQ_HIP_CHECK(hipStreamWaitEvent(sst, ev, 0));
+        return (int)SQ_OK;
+    };
+    auto run_tn = [&](GemmArgs& g) {
+        if (side) g.splitk_ws = b.skws_side;
+        return sq_launch_gemm_tn(g, dtype, sst);
+    };
+    auto bucket_done_side = [&](int i) {                          // bucket i final once the side stream gets here
+        if (n_bucket_events == 0) return (int)SQ_OK;
+        SQ_HIP_CHECK(hipEventRecord((hipEvent_t)bucket_events[i], sst));
+        return (int)SQ_OK;
+    };
 
-    for (int l = c->depth - 1; l >= 0; --l) {
+    float* dXcur = b.dXa;
+    float* dXoth = b.dXb;
+
+    for (int l = top; l >= 0; --l) {
         const sq_vis_layer_offsets& L = lay.layer[l];
+        LayerG lg = b.lg[l];
+        if (!lp) { lg.dXin_lp = dXcur; lg.dX1_lp = dXoth; }
         // ---------------- FeedForward: X2 = GELU(LN(X1) W1^T + b1) W2^T + b2 + X1 ----------------
-        { GemmArgs g = gemm_tn(dXcur_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); g.colsum_a = Gp_(L.ff2_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
+        RUN(ready());
+        { GemmArgs g = gemm_tn(lg.dXin_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); g.colsum_a = Gp_(L.ff2_b); RUN(run_tn(g)); }
         {   // dU = (dX2 . W2) * GELU'(U)
-            GemmArgs g = gemm(dXcur_lp, D, b.wt[l].ff2, D, nullptr, D, M, D, D);
-            g.C = b.dU; g.out_dtype = dtype; g.gelu_grad_of = w.U[l]; g.ldgg = D;
+            GemmArgs g = gemm(lg.dXin_lp, D, b.wt[l].ff2, D, nullptr, D, M, D, D);
+            g.C = lg.dU; g.out_dtype = dtype; g.gelu_grad_of = w.U[l]; g.ldgg = D;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        { GemmArgs g = gemm_tn(b.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); g.colsum_a = Gp_(L.ff1_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-        { GemmArgs g = gemm(b.dU, D, b.wt[l].ff1, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
+        RUN(ready());
+        { GemmArgs g = gemm_tn(lg.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); g.colsum_a = Gp_(L.ff1_b); RUN(run_tn(g)); }
+        { GemmArgs g = gemm(lg.dU, D, b.wt[l].ff1, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
         // dX1 = dX2 + dLN(dY)
-        RUN(sq_k_ln_rows_bwd(b.dY, w.X1[l], Pf(L.ffln_g), dXcur, dXoth, lp ? (bf16_t*)dXoth_lp : nullptr, Gp_(L.ffln_g),
+        RUN(sq_k_ln_rows_bwd(b.dY, w.X1[l], Pf(L.ffln_g), dXcur, dXoth, lp ? (bf16_t*)lg.dX1_lp : nullptr, Gp_(L.ffln_g),
                              Gp_(L.ffln_b), b.red_ws, M, D, st));
-        float* dX1 = dXoth; void* dX1_lp = dXoth_lp;
+        float* dX1 = dXoth;
 
         // ---------------- projection: X1 = O Wp^T + bp + X ----------------
-        { GemmArgs g = gemm_tn(dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); g.colsum_a = Gp_(L.proj_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
+        RUN(ready());
+        { GemmArgs g = gemm_tn(lg.dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); g.colsum_a = Gp_(L.proj_b); RUN(run_tn(g)); }
         {   // dP = (dX1 . Wp) * GELU'(P)
-            GemmArgs g = gemm(dX1_lp, D, b.wt[l].proj, D, nullptr, HD, M, HD, D);
-            g.C = b.dP; g.out_dtype = dtype; g.gelu_grad_of = w.P[l]; g.ldgg = HD;
+            GemmArgs g = gemm(lg.dX1_lp, D, b.wt[l].proj, D, nullptr, HD, M, HD, D);
+            g.C = lg.dP; g.out_dtype = dtype; g.gelu_grad_of = w.P[l]; g.ldgg = HD;
             RUN(sq_launch_gemm(g, dtype, st));
         }
         // ---------------- combiner: P_h = Lf_h Wc_h[:, :64]^T + Ts_h Wc_h[:, 64:]^T + bc_h ----------------
-        RUN(sq_k_group_sum(b.dP, dtype, B, N, HD, 1.0f, b.dCs, st));       // dCs[b] = sum_n dP[b, n]
+        RUN(ready());
+        {   // dWc_h[:, :64] = dP_h^T . Lf_h
+            GemmArgs g = gemm_tn(lg.dP, HD, w.Lf[l], HD, Gp_(L.c_w), 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, M);
+            g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
+            RUN(run_tn(g));
+        }
+        RUN(sq_k_group_sum(lg.dP, dtype, B, N, HD, 1.0f, b.dCs, st));       // dCs[b] = sum_n dP[b, n]
         RUN(sq_k_colsum(b.dCs, SQ_F32, B, HD, HD, b.red_ws, Gp_(L.c_b), st));
         {   // dLf_h = dP_h . Wc_h[:, :64]
-            GemmArgs g = gemm(b.dP, HD, b.wt[l].wc_lf, SQ_HEAD_DIM, b.dLf, HD, M, SQ_HEAD_DIM, SQ_HEAD_DIM);
+            GemmArgs g = gemm(lg.dP, HD, b.wt[l].wc_lf, SQ_HEAD_DIM, b.dLf, HD, M, SQ_HEAD_DIM, SQ_HEAD_DIM);
             g.a_bytes = (size_t)M * HD * es; g.b_bytes = (size_t)H * 64 * 64 * es;
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        {   // dWc_h[:, :64] = dP_h^T . Lf_h
-            GemmArgs g = gemm_tn(b.dP, HD, w.Lf[l], HD, Gp_(L.c_w), 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, M);
-            g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
-            RUN(sq_launch_gemm_tn(g, dtype, st));
-        }
         // ---------------- summary branch ----------------
-        if (lp) RUN(sq_k_cast_pad(b.dCs, HD, b.dCs_lp, dtype, HD, B, HD, st));
+        if (lp) RUN(sq_k_cast_pad(b.dCs, HD, lg.dCs_lp, dtype, HD, B, HD, st));
+        RUN(ready());
+        {   // dWc_h[:, 64:] = dCs_h^T . Ts_h
+            GemmArgs g = gemm_tn(lg.dCs_lp, HD, w.Ts[l], HD, Gp_(L.c_w) + SQ_HEAD_DIM, 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, B);
+            g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
+            RUN(run_tn(g));
+        }
         {   // dTs_h = dCs_h . Wc_h[:, 64:]
-            GemmArgs g = gemm(b.dCs_lp, HD, b.wt[l].wc_ts, SQ_HEAD_DIM, b.dTs, HD, B, SQ_HEAD_DIM, SQ_HEAD_DIM);
+            GemmArgs g = gemm(lg.dCs_lp, HD, b.wt[l].wc_ts, SQ_HEAD_DIM, b.dTs, HD, B, SQ_HEAD_DIM, SQ_HEAD_DIM);
             g.a_bytes = (size_t)B * HD * es; g.b_bytes = (size_t)H * 64 * 64 * es;
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        {   // dWc_h[:, 64:] = dCs_h^T . Ts_h
-            GemmArgs g = gemm_tn(b.dCs_lp, HD, w.Ts[l], HD, Gp_(L.c_w) + SQ_HEAD_DIM, 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, B);
-            g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
-            RUN(sq_launch_gemm_tn(g, dtype, st));
-        }
-        RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), b.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), b.red_ws, B, HD, st));
-        { GemmArgs g = gemm_tn(b.dSm, HD, w.Xbar[l], D, Gp_(L.s_w), D, HD, D, B); g.colsum_a = Gp_(L.s_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
+        RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), lg.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), b.red_ws, B, HD, st));
+        RUN(ready());
+        { GemmArgs g = gemm_tn(lg.dSm, HD, w.Xbar[l], D, Gp_(L.s_w), D, HD, D, B); g.colsum_a = Gp_(L.s_b); RUN(run_tn(g)); }
         {   // dXbar / N   (Xbar = mean_n X: every token of the slide receives dXbar / N)
-            GemmArgs g = gemm(b.dSm, HD, b.wt[l].s, HD, b.dXbar, D, B, D, HD);
+            GemmArgs g = gemm(lg.dSm, HD, b.wt[l].s, HD, b.dXbar, D, B, D, HD);
             g.alpha = 1.0f / (float)N;
             RUN(sq_launch_gemm(g, dtype, st));
         }
         // ---------------- local branch ----------------
-        RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), b.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.red_ws, M, HD, st));
-        { GemmArgs g = gemm_tn(b.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-        if (l > 0) RUN(bucket_done(c->depth - l));
+        RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), lg.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.red_ws, M, HD, st));
+        RUN(ready());       // (also covers every LayerNorm / bias gradient the main stream wrote for this layer)
+        { GemmArgs g = gemm_tn(lg.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(run_tn(g)); }
+        if (l > 0) RUN(bucket_done_side(c->depth - l));
         {   // dXin = dF . Wf + dX1 (residual) + dXbar/N (per-slide row bias)
-            GemmArgs g = gemm(b.dF, HD, b.wt[l].f, HD, dXcur, D, M, D, HD);
+            GemmArgs g = gemm(lg.dF, HD, b.wt[l].f, HD, dXcur, D, M, D, HD);
             g.res = dX1; g.ldres = D; g.rowbias = b.dXbar; g.ldrb = D; g.rows_per_group = N;
-            g.C2 = lp ? (bf16_t*)dXcur_lp : nullptr; g.ldc2 = D;
+            g.C2 = (lp && l > 0) ? (bf16_t*)b.lg[l - 1].dXin_lp : nullptr; g.ldc2 = D;
             RUN(sq_launch_gemm(g, dtype, st));
         }
+        // fp32 keeps the gradient in dXcur for the next layer (read as its dXin); dX1 lived in dXoth: no swap needed
     }
     RUN(sq_k_batch_sum(dXcur, gp + lay.pos, B, N * D, st));       // pos_emb1D is added to every slide
+    if (side) {                                                    // every dW is final before anything after this call
+        hipEvent_t ev = side->events[ev_next++];
+        SQ_HIP_CHECK(hipEventRecord(ev, sst));
+        SQ_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
+    }
     RUN(bucket_done(c->depth));
     if (grad_x) SQ_HIP_CHECK(hipMemcpyAsync(grad_x, dXcur, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
 #undef RUN
