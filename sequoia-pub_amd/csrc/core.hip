@@ -1,5 +1,6 @@
 // Error reporting and device probing for libsequoia_hip.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -60,7 +61,7 @@ int sq_prof_begin(const char* name, double flops, double bytes, hipStream_t st) 
     if (!g_prof_on) return -1;
     ProfRec r{get_event(), get_event(), name, flops, bytes};
     if (!r.a || !r.b) return -1;
-    hipEventRecord(r.a, st);
+    (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
     return (int)g_recs.size() - 1;
 }
@@ -68,7 +69,7 @@ int sq_prof_begin(const char* name, double flops, double bytes, hipStream_t st) 
 void sq_prof_end(int idx, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (idx < 0 || idx >= (int)g_recs.size()) return;
-    hipEventRecord(g_recs[idx].b, st);
+    (void)hipEventRecord(g_recs[idx].b, st);
 }
 
 extern "C" int sq_prof_enable(int on) {
@@ -107,4 +108,30 @@ extern "C" int sq_prof_report(char* buf, size_t cap) {
     SQ_REQUIRE(buf && s.size() + 1 <= cap, "prof_report: buffer of %zu bytes too small (%zu needed)", cap, s.size() + 1);
     memcpy(buf, s.c_str(), s.size() + 1);
     return SQ_OK;
+}
+
+namespace {
+struct SideSlot { hipStream_t stream = nullptr; std::vector<hipEvent_t> events; SqSideStream view{}; };
+std::mutex g_side_mu;
+std::map<std::pair<int, int>, SideSlot> g_side;
+}  // namespace
+
+SqSideStream* sq_side_stream(int which, int n_events) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SideSlot& s = g_side[{dev, which}];
+    if (!s.stream && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    while ((int)s.events.size() < n_events) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        s.events.push_back(e);
+    }
+    s.view.stream = s.stream; s.view.events = s.events.data(); s.view.n_events = (int)s.events.size();
+    return &s.view;
+}
+
+bool sq_env_flag(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] && v[0] != '0';
 }

@@ -15,6 +15,12 @@
 
 void sq_set_error(const char* fmt, ...);
 bool sq_prof_on();
+
+// Helper streams of the library (per device, created on first use, non-blocking) with a pool of timing-less events:
+// independent branches of a pass run beside its main chain; the caller's stream hands work over with events.
+struct SqSideStream { hipStream_t stream; hipEvent_t* events; int n_events; };
+SqSideStream* sq_side_stream(int which, int n_events);      // which = 0, 1; nullptr on failure
+bool sq_env_flag(const char* name);                           // set and not "0"
 int sq_prof_begin(const char* name, double flops, double bytes, hipStream_t st);
 void sq_prof_end(int idx, hipStream_t st);
 

@@ -143,6 +143,9 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
     auto Pf = [&](int64_t off) { return params + off; };
 
     if (int e = sq_k_add_pos(x, Pf(lay.pos), w.Xin[0], lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
+    SqSideStream* fs = (lp && !sq_env_flag("SQ_FWD_ONE_STREAM")) ? sq_side_stream(1, 4 * SQ_MAX_DEPTH) : nullptr;
+    hipStream_t s2 = fs ? fs->stream : st;
+    int ev_next = 0;
 
     for (int l = 0; l < c->depth; ++l) {
         const sq_vis_layer_offsets& L = lay.layer[l];
@@ -152,7 +155,29 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
         float* Xout = w.Xin[save ? l + 1 : 0];
         void* Xout_lp = w.Xin_lp[save ? l + 1 : 0];
 
-        if (int e = sq_k_token_mean(Xin, w.Xbar32[s], lp ? (bf16_t*)w.Xbar[s] : nullptr, B, N, D, st)) return e;
+        // summary branch (per-slide tensors, four small launches) on a helper stream beside the f projection
+        hipEvent_t ev_cs = nullptr;
+        if (fs) {
+            hipEvent_t ev = fs->events[ev_next++];
+            SQ_HIP_CHECK(hipEventRecord(ev, st));
+            SQ_HIP_CHECK(hipStreamWaitEvent(s2, ev, 0));
+        }
+        if (int e = sq_k_token_mean(Xin, w.Xbar32[s], lp ? (bf16_t*)w.Xbar[s] : nullptr, B, N, D, s2)) return e;
+        {   // Sm = Xbar Ws^T + bs
+            GemmArgs g; g.A = w.Xbar[s]; g.lda = D; g.a_bytes = (size_t)B * D * es;
+            g.B = W(L.s_w); g.ldb = D; g.b_bytes = Wrem(L.s_w); g.bias = Pf(L.s_b);
+            g.C = w.Sm[s]; g.ldc = HD; g.M = B; g.N = HD; g.K = D; g.splitk_ws = w.skws; g.splitk_ws_bytes = w.skws_bytes;
+            if (int e = sq_launch_gemm(g, dtype, s2)) return e;
+        }
+        if (int e = sq_k_ln64_gelu(w.Sm[s], Pf(L.lns_g), Pf(L.lns_b), w.Ts[s], dtype, B, HD, s2)) return e;
+        {   // Cs[b, h] = Ts[b, h] . Wc_h[:, 64:128]^T + bc_h     (cat order: [local, summary], tformer_lin.py:24)
+            GemmArgs g; g.A = w.Ts[s]; g.lda = HD; g.a_bytes = (size_t)B * HD * es; g.sA = SQ_HEAD_DIM;
+            g.B = W(L.c_w + SQ_HEAD_DIM); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w + SQ_HEAD_DIM); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
+            g.bias = Pf(L.c_b); g.sBias = SQ_HEAD_DIM;
+            g.C = w.Cs[s]; g.ldc = HD; g.sC = SQ_HEAD_DIM; g.M = B; g.N = SQ_HEAD_DIM; g.K = SQ_HEAD_DIM; g.batch = H;
+            if (int e = sq_launch_gemm(g, dtype, s2)) return e;
+        }
+        if (fs) { ev_cs = fs->events[ev_next++]; SQ_HIP_CHECK(hipEventRecord(ev_cs, s2)); }
         {   // F = X Wf^T + bf
             GemmArgs g; g.A = Xin_t; g.lda = D; g.a_bytes = (size_t)M * D * es;
             g.B = W(L.f_w); g.ldb = D; g.b_bytes = Wrem(L.f_w); g.bias = Pf(L.f_b);
@@ -160,20 +185,7 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
         if (int e = sq_k_ln64_gelu(w.F[s], Pf(L.lnf_g), Pf(L.lnf_b), w.Lf[s], dtype, M, HD, st)) return e;
-        {   // Sm = Xbar Ws^T + bs
-            GemmArgs g; g.A = w.Xbar[s]; g.lda = D; g.a_bytes = (size_t)B * D * es;
-            g.B = W(L.s_w); g.ldb = D; g.b_bytes = Wrem(L.s_w); g.bias = Pf(L.s_b);
-            g.C = w.Sm[s]; g.ldc = HD; g.M = B; g.N = HD; g.K = D; g.splitk_ws = w.skws; g.splitk_ws_bytes = w.skws_bytes;
-            if (int e = sq_launch_gemm(g, dtype, st)) return e;
-        }
-        if (int e = sq_k_ln64_gelu(w.Sm[s], Pf(L.lns_g), Pf(L.lns_b), w.Ts[s], dtype, B, HD, st)) return e;
-        {   // Cs[b, h] = Ts[b, h] . Wc_h[:, 64:128]^T + bc_h     (cat order: [local, summary], tformer_lin.py:24)
-            GemmArgs g; g.A = w.Ts[s]; g.lda = HD; g.a_bytes = (size_t)B * HD * es; g.sA = SQ_HEAD_DIM;
-            g.B = W(L.c_w + SQ_HEAD_DIM); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w + SQ_HEAD_DIM); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
-            g.bias = Pf(L.c_b); g.sBias = SQ_HEAD_DIM;
-            g.C = w.Cs[s]; g.ldc = HD; g.sC = SQ_HEAD_DIM; g.M = B; g.N = SQ_HEAD_DIM; g.K = SQ_HEAD_DIM; g.batch = H;
-            if (int e = sq_launch_gemm(g, dtype, st)) return e;
-        }
+        if (ev_cs) SQ_HIP_CHECK(hipStreamWaitEvent(st, ev_cs, 0));
         {   // O[m, h] = GELU(Lf[m, h] . Wc_h[:, 0:64]^T + Cs[slide(m), h])
             GemmArgs g; g.A = w.Lf[s]; g.lda = HD; g.a_bytes = (size_t)M * HD * es; g.sA = SQ_HEAD_DIM;
             g.B = W(L.c_w); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;

@@ -42,32 +42,9 @@ struct BwdBufs {
     float* red_ws;                   // reduction scratch
     float* skws; size_t skws_bytes;  // split-K scratch (dW products have K = tokens and few output tiles)
     float* skws_side;                // the same for the second stream
+    float* red_ws2; float* skws2; size_t skws2_bytes;   // scratch of the summary-branch stream
     size_t bytes;
 };
-
-// one helper stream + event pool per device, created on first use
-struct SideStream { hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
-
-SideStream* side_stream_get(int n_events) {
-    static std::mutex mu;
-    static std::map<int, SideStream> table;
-    std::lock_guard<std::mutex> lk(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    SideStream& s = table[dev];
-    if (!s.stream && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    while ((int)s.events.size() < n_events) {
-        hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        s.events.push_back(e);
-    }
-    return &s;
-}
-
-bool sq_env_flag(const char* name) {
-    const char* v = getenv(name);
-    return v && v[0] && v[0] != '0';
-}
 
 void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) {
     Arena a{base, 0};
@@ -114,6 +91,9 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
     o->skws_bytes = (size_t)16 * W * W * 4;
     o->skws = (float*)a.take(o->skws_bytes);
     o->skws_side = lp ? (float*)a.take(o->skws_bytes) : o->skws;
+    o->red_ws2 = lp ? (float*)a.take(red * 4) : o->red_ws;
+    o->skws2_bytes = lp ? (size_t)32 * B * W * 4 : o->skws_bytes;
+    o->skws2 = lp ? (float*)a.take(o->skws2_bytes) : o->skws;
     o->bytes = sq_align_up(a.off, 256);
 }
 
@@ -243,10 +223,12 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
     // phase (all of its blocks are resident at once and move in lock-step): a dW product running beside a dX
     // product fills each other's idle phase.  The main stream records an event when an operand is final; the side
     // stream waits for it.  Operands the side stream reads exist per layer (LayerG), so the dX chain never waits.
-    SideStream* side = nullptr;
+    SqSideStream* side = nullptr;      // weight gradients
+    SqSideStream* side2 = nullptr;     // summary branch (small per-slide kernels)
     if (lp && !sq_env_flag("SQ_BWD_ONE_STREAM")) {
-        side = side_stream_get(7 * SQ_MAX_DEPTH + 1);
-        SQ_REQUIRE(side != nullptr, "vis_backward: could not create the weight-gradient stream");
+        side = sq_side_stream(0, 7 * SQ_MAX_DEPTH + 1);
+        side2 = sq_side_stream(1, 4 * SQ_MAX_DEPTH);
+        SQ_REQUIRE(side != nullptr && side2 != nullptr, "vis_backward: could not create the helper streams");
     }
     hipStream_t sst = side ? side->stream : st;
     int ev_next = 0;
@@ -256,6 +238,16 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         hipEvent_t ev = side->events[ev_next++];
         SQ_HIP_CHECK(hipEventRecord(ev, st));
         SQ_HIP_CHECK(hipStreamWaitEvent(sst, ev, 0));
+        return (int)SQ_OK;
+    };
+    hipStream_t s2 = side2 ? side2->stream : st;
+    float* red2 = side2 ? b.red_ws2 : b.red_ws;
+    int ev2_next = 0;
+    auto handoff = [&](hipStream_t from, hipStream_t to) {        // `to` may use what `from` has produced so far
+        if (!side2 || from == to) return (int)SQ_OK;
+        hipEvent_t ev = side2->events[ev2_next++];
+        SQ_HIP_CHECK(hipEventRecord(ev, from));
+        SQ_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
         return (int)SQ_OK;
     };
     auto run_tn = [&](GemmArgs& g) {
@@ -306,17 +298,12 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
             RUN(run_tn(g));
         }
-        RUN(sq_k_group_sum(lg.dP, dtype, B, N, HD, 1.0f, b.dCs, st));       // dCs[b] = sum_n dP[b, n]
-        RUN(sq_k_colsum(b.dCs, SQ_F32, B, HD, HD, b.red_ws, Gp_(L.c_b), st));
-        {   // dLf_h = dP_h . Wc_h[:, :64]
-            GemmArgs g = gemm(lg.dP, HD, b.wt[l].wc_lf, SQ_HEAD_DIM, b.dLf, HD, M, SQ_HEAD_DIM, SQ_HEAD_DIM);
-            g.a_bytes = (size_t)M * HD * es; g.b_bytes = (size_t)H * 64 * 64 * es;
-            g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
-            RUN(sq_launch_gemm(g, dtype, st));
-        }
-        // ---------------- summary branch ----------------
-        if (lp) RUN(sq_k_cast_pad(b.dCs, HD, lg.dCs_lp, dtype, HD, B, HD, st));
-        RUN(ready());
+        // ---------------- summary branch: per-slide tensors, small launches -> third stream, beside the local branch
+        RUN(handoff(st, s2));
+        RUN(sq_k_group_sum(lg.dP, dtype, B, N, HD, 1.0f, b.dCs, s2));       // dCs[b] = sum_n dP[b, n]
+        RUN(sq_k_colsum(b.dCs, SQ_F32, B, HD, HD, red2, Gp_(L.c_b), s2));
+        if (lp) RUN(sq_k_cast_pad(b.dCs, HD, lg.dCs_lp, dtype, HD, B, HD, s2));
+        RUN(handoff(s2, sst));
         {   // dWc_h[:, 64:] = dCs_h^T . Ts_h
             GemmArgs g = gemm_tn(lg.dCs_lp, HD, w.Ts[l], HD, Gp_(L.c_w) + SQ_HEAD_DIM, 2 * SQ_HEAD_DIM, SQ_HEAD_DIM, SQ_HEAD_DIM, B);
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
@@ -326,20 +313,31 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
             GemmArgs g = gemm(lg.dCs_lp, HD, b.wt[l].wc_ts, SQ_HEAD_DIM, b.dTs, HD, B, SQ_HEAD_DIM, SQ_HEAD_DIM);
             g.a_bytes = (size_t)B * HD * es; g.b_bytes = (size_t)H * 64 * 64 * es;
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
-            RUN(sq_launch_gemm(g, dtype, st));
+            g.splitk_ws = b.skws2; g.splitk_ws_bytes = b.skws2_bytes;
+            RUN(sq_launch_gemm(g, dtype, s2));
         }
-        RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), lg.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), b.red_ws, B, HD, st));
-        RUN(ready());
+        RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), lg.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), red2, B, HD, s2));
+        RUN(handoff(s2, sst));
         { GemmArgs g = gemm_tn(lg.dSm, HD, w.Xbar[l], D, Gp_(L.s_w), D, HD, D, B); g.colsum_a = Gp_(L.s_b); RUN(run_tn(g)); }
         {   // dXbar / N   (Xbar = mean_n X: every token of the slide receives dXbar / N)
             GemmArgs g = gemm(lg.dSm, HD, b.wt[l].s, HD, b.dXbar, D, B, D, HD);
             g.alpha = 1.0f / (float)N;
+            g.splitk_ws = b.skws2; g.splitk_ws_bytes = b.skws2_bytes;
+            RUN(sq_launch_gemm(g, dtype, s2));
+        }
+        hipEvent_t ev_xbar = nullptr;
+        if (side2) { ev_xbar = side2->events[ev2_next++]; SQ_HIP_CHECK(hipEventRecord(ev_xbar, s2)); }
+        // ---------------- local branch (main stream) ----------------
+        {   // dLf_h = dP_h . Wc_h[:, :64]
+            GemmArgs g = gemm(lg.dP, HD, b.wt[l].wc_lf, SQ_HEAD_DIM, b.dLf, HD, M, SQ_HEAD_DIM, SQ_HEAD_DIM);
+            g.a_bytes = (size_t)M * HD * es; g.b_bytes = (size_t)H * 64 * 64 * es;
+            g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        // ---------------- local branch ----------------
         RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), lg.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.red_ws, M, HD, st));
-        RUN(ready());       // (also covers every LayerNorm / bias gradient the main stream wrote for this layer)
+        RUN(ready());       // (the side stream has by now also waited for every summary-branch gradient of this layer)
         { GemmArgs g = gemm_tn(lg.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(run_tn(g)); }
+        if (ev_xbar) SQ_HIP_CHECK(hipStreamWaitEvent(st, ev_xbar, 0));
         if (l > 0) RUN(bucket_done_side(c->depth - l));
         {   // dXin = dF . Wf + dX1 (residual) + dXbar/N (per-slide row bias)
             GemmArgs g = gemm(lg.dF, HD, b.wt[l].f, HD, dXcur, D, M, D, HD);
