@@ -11,6 +11,8 @@ import ctypes
 import math
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -111,7 +113,7 @@ class ResNet50(nn.Module):
             raise NotImplementedError("sequoia-pub_amd ResNet50 runs in eval mode only (as the reference does)")
         return super().train(mode)
 
-    def _run(self, patches_u8=None, x_f32=None):
+    def _run(self, patches_u8=None, x_f32=None, slot=0):
         _lib.require_gpu()
         w, b = self._pack()
         if not w.is_cuda:
@@ -123,12 +125,15 @@ class ResNet50(nn.Module):
         need = _lib.lib().sq_resnet50_workspace_bytes(self.compute_dtype, n, S)
         if need == 0:
             raise ValueError(f"unsupported patch size {S} (need a multiple of 32, >= 224)")
-        if self._ws is None or self._ws.numel() < need or self._ws.device != w.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=w.device)
+        if not isinstance(self._ws, dict):
+            self._ws = {}
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need or ws.device != w.device:
+            ws = self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=w.device)
         with torch.cuda.device(w.device):
             _lib.check(_lib.lib().sq_resnet50_extract(self.compute_dtype, _lib.ptr(w), _lib.ptr(b), _lib.ptr(patches_u8),
-                                                      _lib.ptr(x_f32), n, S, _lib.ptr(feats), _lib.ptr(self._ws),
-                                                      self._ws.numel(), _lib.stream_ptr(w.device)))
+                                                      _lib.ptr(x_f32), n, S, _lib.ptr(feats), _lib.ptr(ws),
+                                                      ws.numel(), _lib.stream_ptr(w.device)))
         return feats
 
     @torch.no_grad()
@@ -144,9 +149,28 @@ class ResNet50(nn.Module):
         matrix); larger sub-batches measured faster (38.1 slides/s at 500 vs 34.9 at 200) -- longer grids, fewer tails."""
         dev = self.conv1.weight.device
         patches = torch.as_tensor(patches)
-        outs = []
-        for i in range(0, patches.shape[0], sub_batch):
-            outs.append(self._run(patches_u8=patches[i:i + sub_batch].to(dev).contiguous()))
+        chunks = [patches[i:i + sub_batch] for i in range(0, patches.shape[0], sub_batch)]
+        if len(chunks) == 1 or not patches.is_cuda:
+            return torch.cat([self._run(patches_u8=c.to(dev).contiguous()) for c in chunks], 0)
+        # Two sub-batches in flight on two streams (own workspaces): every convolution of the chain is one launch
+        # that depends on the previous one, so a single chain leaves the chip idle in each launch's ramp-up, tail and
+        # store-drain phase; a second, independent chain fills those.
+        main = torch.cuda.current_stream(dev)
+        ns = max(1, int(os.environ.get("SQ_RESNET_STREAMS", "2")))
+        if getattr(self, "_streams", None) is None or self._streams[0].device != dev or len(self._streams) != ns:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        start = torch.cuda.Event()
+        start.record(main)
+        outs = [None] * len(chunks)
+        for i, c in enumerate(chunks):
+            st = self._streams[i % ns]
+            st.wait_event(start)
+            with torch.cuda.stream(st):
+                outs[i] = self._run(patches_u8=c.contiguous(), slot=i % ns)
+        for st in self._streams:
+            main.wait_stream(st)
+        for o in outs:
+            o.record_stream(main)
         return torch.cat(outs, 0)
 
     def forward(self, x):
