@@ -75,13 +75,27 @@ def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=
     mem = torch.from_numpy(members).to(dev)
     W = mem.shape[0]
     win_pred = torch.empty(W, G, dtype=torch.float32, device=dev)
-    for s in range(0, W, batch_windows):
-        m = mem[s:s + batch_windows]
-        x = feats_pad[m]                                                        # [w, 100, D]
-        if literal_2d:
-            # reference: model(features_all) with a 2-D [100, D] tensor, then [0]  -> depends on tile 0 only
-            x = x[:, 0:1, :].expand(-1, 100, -1).contiguous()
-        win_pred[s:s + m.shape[0]] = model(x)
+    # two batches of windows in flight on two streams (own workspaces): each forward is a chain of dependent
+    # launches, a second chain fills the ramp-up / store-drain phases of the first
+    main = torch.cuda.current_stream(dev)
+    streams = model.__dict__.setdefault("_spatial_streams", None)
+    if streams is None or streams[0].device != dev:
+        streams = model.__dict__["_spatial_streams"] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    start = torch.cuda.Event()
+    start.record(main)
+    model._params_lp()                                                         # refresh the bf16 shadow once, on the main stream
+    for i, s in enumerate(range(0, W, batch_windows)):
+        st = streams[i % 2]
+        st.wait_event(start)
+        with torch.cuda.stream(st):
+            m = mem[s:s + batch_windows]
+            x = feats_pad[m]                                                    # [w, 100, D]
+            if literal_2d:
+                # reference: model(features_all) with a 2-D [100, D] tensor, then [0]  -> depends on tile 0 only
+                x = x[:, 0:1, :].expand(-1, 100, -1).contiguous()
+            win_pred[s:s + m.shape[0]] = model._run_forward(x, False, slot=i % 2)
+    for st in streams:
+        main.wait_stream(st)
     lists, counts = tile_window_lists(mem, n_tiles, dev)
     out = torch.empty(n_tiles, G, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

@@ -252,17 +252,24 @@ class ViS(nn.Module, PyTorchModelHubMixin):
             self._lp_version = self.flat._version
         return self._lp
 
-    def _workspace(self, batch, save):
+    def _workspace(self, batch, save, slot=0):
         key = (batch, bool(save), self.compute_dtype, self.flat.device)
         need = getattr(_lib.lib(), self._C_WS)(ctypes.byref(self.cfg), self.compute_dtype, batch, int(save))
         if need == 0:
             _lib.check(-1)
+        if slot:                     # extra inference workspaces: forwards in flight on several streams
+            extra = self.__dict__.setdefault("_ws_extra", {})
+            ws, k = extra.get(slot, (None, None))
+            if ws is None or k != key or ws.numel() < need:
+                ws = torch.empty(need, dtype=torch.uint8, device=self.flat.device)
+                extra[slot] = (ws, key)
+            return ws
         if self._ws is None or self._ws_key != key or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.flat.device)
             self._ws_key = key
         return self._ws
 
-    def _run_forward(self, x, save):
+    def _run_forward(self, x, save, slot=0):
         _lib.require_gpu()
         if not self.flat.is_cuda:
             raise _lib.SequoiaHipError("ViS parameters are on the CPU: call .to('cuda') first (no CPU fallback)")
@@ -272,7 +279,7 @@ class ViS(nn.Module, PyTorchModelHubMixin):
         if N != self.cfg.num_clusters or D != self._dim():
             raise ValueError(f"expected [B, {self.cfg.num_clusters}, {self._dim()}] tokens, got {tuple(x.shape)}")
         out = torch.empty(B, self.cfg.num_outputs, dtype=torch.float32, device=x.device)
-        ws = self._workspace(B, save)
+        ws = self._workspace(B, save, slot)
         lp = self._params_lp()
         with torch.cuda.device(x.device):
             _lib.check(getattr(_lib.lib(), self._C_FWD)(ctypes.byref(self.cfg), self.compute_dtype, _lib.ptr(self.flat),
