@@ -51,3 +51,19 @@ def test_forward_extract_float_input_and_batch_consistency():
     with torch.no_grad():
         ref = ro.forward_extract(sd, x).numpy()
     assert rel_err(fused, ref) < 1e-4
+
+
+def test_two_streams_in_flight_equal_one(monkeypatch):
+    """extract_patches_u8 keeps two sub-batches in flight on two streams: same bits as the sequential run."""
+    _lib.require_gpu()
+    from sequoia_pub_amd import synth
+    torch.manual_seed(3)
+    rn = resnet50(pretrained=False, compute_dtype="bf16").to("cuda:0").eval()
+    patches = torch.from_numpy(synth.patches_u8(5, 24, 224)).cuda()
+    a = rn.extract_patches_u8(patches, sub_batch=7)              # 4 chunks, ragged last one, 2 streams
+    monkeypatch.setenv("SQ_RESNET_STREAMS", "1")
+    b = rn.extract_patches_u8(patches, sub_batch=7)
+    c = rn.extract_patches_u8(patches, sub_batch=24)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.equal(a, c)                                      # sub-batching itself does not change a patch's features

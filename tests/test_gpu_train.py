@@ -187,3 +187,27 @@ def test_full_size_grads_vs_oracle(mode, tol):
             worst = (k, e)
     print(f"full-size grads {mode}: worst per-tensor rel err {worst[1]:.3e} at {worst[0]}; loss {float(loss):.5f} vs {float(loss_ref):.5f}")
     assert worst[1] < tol, worst
+
+
+def test_helper_streams_do_not_change_results(monkeypatch):
+    """bf16 training step at a realistic size: weight gradients / summary branch on helper streams vs everything on
+    one stream must give bit-identical losses and parameters (the kernels are deterministic; streams only reorder)."""
+    _lib.require_gpu()
+    cfg = dict(num_outputs=1000, input_dim=256, depth=3, nheads=4, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    x = torch.randn(8, 100, 256, generator=torch.Generator().manual_seed(1)).cuda()
+    y = (torch.rand(8, 1000, generator=torch.Generator().manual_seed(2)) * 8).cuda()
+
+    def run():
+        torch.manual_seed(4)
+        m = ViS(**cfg, device="cuda:0", compute_dtype="bf16").to("cuda:0")
+        st = sq_train.FusedTrainStep(m, lr=1e-3)
+        losses = [float(st.step(x, y)[0]) for _ in range(4)]
+        torch.cuda.synchronize()
+        return losses, m.flat.detach().clone()
+
+    l_multi, p_multi = run()
+    monkeypatch.setenv("SQ_BWD_ONE_STREAM", "1")
+    monkeypatch.setenv("SQ_FWD_ONE_STREAM", "1")
+    l_one, p_one = run()
+    assert l_multi == l_one
+    assert torch.equal(p_multi, p_one)
