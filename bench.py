@@ -56,6 +56,9 @@ def timed_region(step_fn, steps, warmup, world, device):
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
+        if os.environ.get("SQ_BENCH_STEPTIMES"):       # debugging aid: per-step wall time (adds a sync per step)
+            torch.cuda.synchronize()
+            print(f"step done at {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
     barrier_sync(world)
     dt = time.perf_counter() - t0
     if world > 1:
@@ -216,16 +219,36 @@ def workload_pipeline(args, rank, world, device):
     cfg = dict(VIS_CFG, input_dim=2048)
     vis = ViS(**cfg, num_clusters=100, device=str(device), compute_dtype=args.dtype).to(device).eval()
     pipe = SlidePipeline(rn, vis, sub_batch=args.sub_batch)
-    slides = [torch.from_numpy(synth.patches_u8(rank * nslides + i, npatch, 224)).to(device) for i in range(nslides)]
+    host = [torch.from_numpy(synth.patches_u8(rank * nslides + i, npatch, 224)) for i in range(nslides)]
+    if args.from_host:
+        # PCIe-inclusive variant (reported in DESIGN.md, never `value` of the default run): slides live in pinned host
+        # memory; each step uploads them on a copy stream, slide i+1's upload under slide i's embedding
+        host = [h.pin_memory() for h in host]
+        copy_stream = torch.cuda.Stream(device=device)
+        staging = [torch.empty_like(h, device=device) for h in host]
 
-    def step():
-        pipe(slides)
+        def step():
+            main = torch.cuda.current_stream(device)
+            copy_stream.wait_stream(main)    # staging buffers of the previous step are free
+            evs = []
+            with torch.cuda.stream(copy_stream):
+                for h, d in zip(host, staging):
+                    d.copy_(h, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                    evs.append(ev)
+            pipe(list(zip(staging, evs)))    # the pipeline waits for slide i's upload right before embedding it
+    else:
+        slides = [h.to(device) for h in host]
+
+        def step():
+            pipe(slides)
 
     def cpu_baseline():
         from oracle import kmeans_oracle, resnet_oracle, vis_oracle
         sd_r = {k: v.cpu() for k, v in rn.state_dict().items()}
         sd_v = {k: v.cpu() for k, v in vis.state_dict().items()}
-        patches = slides[0][:32].cpu()
+        patches = host[0][:32]
 
         def embed():
             resnet_oracle.embed_patches(sd_r, patches, batch=32)
@@ -244,7 +267,8 @@ def workload_pipeline(args, rank, world, device):
 
     return dict(step=step, slides_per_step=nslides, cpu_baseline=cpu_baseline,
                 config={"workload": "pipeline: 1000 x 224x224 uint8 patches/slide -> ResNet-50 embed -> k-Means(100) -> "
-                                    "ViS(D=2048, depth 6, 16 heads, G=20820) forward (BASELINE config 3), patches resident in HBM",
+                                    "ViS(D=2048, depth 6, 16 heads, G=20820) forward (BASELINE config 3), " +
+                                    ("patches uploaded from pinned host memory every step" if args.from_host else "patches resident in HBM"),
                         "slides_per_step_per_gpu": nslides, "patches_per_slide": npatch,
                         "parallelism": f"slide-sharded x{world}"})
 
@@ -302,6 +326,7 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=500, help="pipeline workload: patches per ResNet launch group")
     ap.add_argument("--grid", type=int, nargs=2, default=[250, 200], help="spatial workload: tile grid")
     ap.add_argument("--batch-windows", type=int, default=1024, help="spatial workload: windows per ViS forward")
+    ap.add_argument("--from-host", action="store_true", help="pipeline workload: upload the patches from pinned host memory every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -33,7 +33,8 @@ class SlidePipeline:
 
     @torch.no_grad()
     def __call__(self, slides_u8):
-        """slides_u8: list of [n_i, S, S, 3] uint8 tensors, or one [S, n, S, S, 3] tensor.
+        """slides_u8: list of [n_i, S, S, 3] uint8 tensors (or (tensor, torch.cuda.Event) pairs whose upload is
+        still in flight on another stream), or one [S, n, S, S, 3] tensor.
         Returns dict(pred [S, G], cluster_features [S, 100, D], labels list).
 
         The k-Means of slide i (small grids, a host check of the convergence flags every few Lloyd
@@ -58,6 +59,9 @@ class SlidePipeline:
 
         pending = None
         for p in slides_u8:
+            if isinstance(p, tuple):               # (tensor, event): an upload still in flight on a copy stream
+                p, uploaded = p
+                main.wait_event(uploaded)
             f = self.embed(p)                      # enqueued first: the GPU has this to chew on ...
             ev = torch.cuda.Event()
             ev.record(main)
