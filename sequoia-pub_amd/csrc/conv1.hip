@@ -17,6 +17,11 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
 constexpr int TP = 8;                    // pooled tile edge
 constexpr int TC = 2 * TP + 1;           // conv tile edge (17)
 constexpr int RW = 40;                   // staged input row pitch in pixels (39 needed + kx = 7 slot)
@@ -82,12 +87,15 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(const Conv1Args p) {
         a_off[i] = ((2 * oy) * RW + 2 * ox + 2 * g) * 8;
     }
 
-    const int S = p.S, OH = S / 2, PH = S / 4;
+    const int S = p.S, PH = S / 4;
     const int tps2 = p.tiles_per_side * p.tiles_per_side;
     constexpr int NPX = (RH * RW + 255) / 256;     // staged pixels per thread (7)
 
     // uint8 source: the NEXT tile's pixels are fetched into registers while this tile is on the MFMA
-    uint8_t pre[NPX][3];
+    // Raw load results only: one 16-bit (channels 0, 1) and one 8-bit (channel 2) load per pixel.  They are split
+    // in commit(), i.e. after the loop's back edge -- any arithmetic on them here would make the wave wait for the
+    // loads before its MFMA phase instead of under it.
+    uint32_t pre01[NPX], pre2[NPX];
     uint32_t pre_ok = 0;
     auto prefetch = [&](int tile) {
         const int img = tile / tps2, tt = tile - img * tps2;
@@ -102,7 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(const Conv1Args p) {
             const int iy = iy0 + r, ix = ix0 + q;
             const bool ok = idx < RH * RW && (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
             const uint8_t* px = base + ((uint32_t)(ok ? iy : 0) * S + (ok ? ix : 0)) * 3;
-            pre[j][0] = px[0]; pre[j][1] = px[1]; pre[j][2] = px[2];
+            uint16_t v01;
+            __builtin_memcpy(&v01, px, 2);
+            pre01[j] = v01; pre2[j] = px[2];
             pre_ok |= ok ? (1u << j) : 0u;
         }
     };
@@ -112,8 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(const Conv1Args p) {
             const int idx = tid + j * 256;
             if (idx < RH * RW) {
                 const bool ok = (pre_ok >> j) & 1;
-                const uint32_t lo = ok ? ((uint32_t)s_lut[pre[j][0]] | ((uint32_t)s_lut[256 + pre[j][1]] << 16)) : 0u;
-                const uint32_t hi = ok ? (uint32_t)s_lut[512 + pre[j][2]] : 0u;
+                const uint32_t c0 = pre01[j] & 0xffu, c1 = (pre01[j] >> 8) & 0xffu, c2 = pre2[j] & 0xffu;
+                const uint32_t lo = ok ? ((uint32_t)s_lut[c0] | ((uint32_t)s_lut[256 + c1] << 16)) : 0u;
+                const uint32_t hi = ok ? (uint32_t)s_lut[512 + c2] : 0u;
                 *reinterpret_cast<u32x2*>(s_in + idx * 8) = u32x2{lo, hi};
             }
         }
@@ -145,12 +156,12 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(const Conv1Args p) {
         __syncthreads();
         if (p.u8 && tile + (int)gridDim.x < p.tiles) prefetch(tile + gridDim.x);
 
-        // ---- 17 x 17 x 64 conv tile on the MFMA
+        // ---- 17 x 17 x 64 conv tile on the MFMA (accumulators start at the folded-BN bias)
         f32x16 acc[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][r] = bias;
 #pragma unroll
         for (int t = 0; t < 14; ++t) {
             const int ky = t >> 1, h = t & 1;
@@ -160,51 +171,46 @@ __global__ __launch_bounds__(256, 2) void conv1_pool_kernel(const Conv1Args p) {
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), wf[t], acc[i], 0, 0, 0);
             }
         }
-        // bias + ReLU -> bf16 conv tile in LDS.  C/D layout: col = l31 (channel), row = (r&3) + 8*(r>>2) + 4*g
+        // bf16 (hardware RNE pack) -> ReLU -> conv tile in LDS.  This phase is VALU-bound (80 values per lane), so it
+        // works on PAIRS: v_cvt_pk_bf16_f32, and ReLU as a packed signed-16-bit max with 0 (a negative bf16 is a
+        // negative int16).  C/D layout: col = l31 (channel), row = (r&3) + 8*(r>>2) + 4*g.
+        {
+            char* dst = s_out + (wm * 160 + 4 * g) * CROW + (wn * 32 + l31) * 2;
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+            for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wm * 160 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                const float v = fmaxf(acc[i][r] + bias, 0.f);
-                *reinterpret_cast<bf16_t*>(s_out + m * CROW + (wn * 32 + l31) * 2) = f32_to_bf16(v);
-            }
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v = {acc[i][r], acc[i][r + 1]};
+                    const i16x2 relu = __builtin_elementwise_max(__builtin_bit_cast(i16x2, __builtin_convertvector(v, bf16x2)), i16x2{0, 0});
+                    const int m0 = i * 32 + (r & 3) + 8 * (r >> 2);               // rows m0 and m0 + 1
+                    *reinterpret_cast<int16_t*>(dst + m0 * CROW) = relu[0];
+                    *reinterpret_cast<int16_t*>(dst + (m0 + 1) * CROW) = relu[1];
+                }
+        }
         __syncthreads();
 
-        // ---- 3 x 3 stride-2 max over the conv tile: thread = (pooled pixel, 16 channels)
+        // ---- 3 x 3 stride-2 max over the conv tile: thread = (pooled pixel, 16 channels).  All values are >= 0, so
+        // bf16 order == unsigned 16-bit order (packed integer max) and 0 stands for the pool's -inf padding; taps
+        // outside the image (first conv row / column of the first tile row / column) are redirected to their valid
+        // neighbour, which cannot change a maximum.
         {
             const int pp = tid >> 2, cg = tid & 3;
             const int py = pp >> 3, px = pp & 7;
-            float best[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) best[e] = -INFINITY;
+            u16x8 b0 = {0, 0, 0, 0, 0, 0, 0, 0}, b1 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int cy = 2 * py + dy, cx = 2 * px + dx;                  // conv pixel inside the tile
-                    const int oy = 2 * TP * ty - 1 + cy, ox = 2 * TP * tx - 1 + cx;   // and in the image (the pool's -inf padding)
-                    if (oy >= 0 && ox >= 0 && oy < OH && ox < OH) {
-                        const char* src = s_out + (cy * TC + cx) * CROW + cg * 32;
-                        const u32x4 a = *reinterpret_cast<const u32x4*>(src), b = *reinterpret_cast<const u32x4*>(src + 16);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            best[2 * e] = fmaxf(best[2 * e], __uint_as_float(a[e] << 16));
-                            best[2 * e + 1] = fmaxf(best[2 * e + 1], __uint_as_float(a[e] & 0xffff0000u));
-                            best[8 + 2 * e] = fmaxf(best[8 + 2 * e], __uint_as_float(b[e] << 16));
-                            best[8 + 2 * e + 1] = fmaxf(best[8 + 2 * e + 1], __uint_as_float(b[e] & 0xffff0000u));
-                        }
-                    }
+                    int cy = 2 * py + dy, cx = 2 * px + dx;                        // conv pixel inside the tile
+                    if (ty == 0 && cy == 0) cy = 1;
+                    if (tx == 0 && cx == 0) cx = 1;
+                    const char* src = s_out + (cy * TC + cx) * CROW + cg * 32;
+                    b0 = __builtin_elementwise_max(b0, *reinterpret_cast<const u16x8*>(src));
+                    b1 = __builtin_elementwise_max(b1, *reinterpret_cast<const u16x8*>(src + 16));
                 }
-            u32x4 o0, o1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {      // exact: the values are bf16 already
-                o0[e] = (__float_as_uint(best[2 * e]) >> 16) | (__float_as_uint(best[2 * e + 1]) & 0xffff0000u);
-                o1[e] = (__float_as_uint(best[8 + 2 * e]) >> 16) | (__float_as_uint(best[8 + 2 * e + 1]) & 0xffff0000u);
-            }
             bf16_t* dst = p.out + (((size_t)img * PH + TP * ty + py) * PH + TP * tx + px) * 64 + cg * 16;
-            *reinterpret_cast<u32x4*>(dst) = o0;
-            *reinterpret_cast<u32x4*>(dst + 8) = o1;
+            *reinterpret_cast<u16x8*>(dst) = b0;
+            *reinterpret_cast<u16x8*>(dst + 8) = b1;
         }
         // the next tile's staging only touches s_in (all MFMA reads are behind the barrier above); its conv
         // tile is written after the next barrier, by which time every thread has finished pooling this one
