@@ -63,16 +63,19 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even, NaN kept quiet
+// round-to-nearest-even through gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the integer
+// add-and-shift formulation costs ~5 VALU ops per value and made bf16-output epilogues VALU-bound)
+typedef float sq_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sq_bf16x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const sq_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sq_bf16x2));
 }
 
 // exact (erf) GELU: torch.nn.GELU() default, tformer_lin.py:20-24,57
