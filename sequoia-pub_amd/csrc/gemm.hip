@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8 + 4);
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            epi_apply<EPI>(p, z, m, e_n, v, e_cnt, false);
+            epi_apply<EPI, sizeof(T) == 2>(p, z, m, e_n, v, e_cnt, false);
         }
         return;
     }
@@ -380,14 +380,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
             }
             if ((EPI & 1) && p.act == SQ_ACT_GELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = sq_gelu<sizeof(T) == 2>(v[e]);
             } else if (p.act == SQ_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             if ((EPI & 2) && gg) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(aux[u][e]);
+                for (int e = 0; e < 8; ++e) v[e] *= sq_gelu_grad<sizeof(T) == 2>(aux[u][e]);
             }
             if (c32) {
                 float* d = c32 + (long long)m * p.ldc + e_n;

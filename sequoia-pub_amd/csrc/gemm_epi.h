@@ -5,8 +5,9 @@
 // Epilogue of one 8-wide chunk (row m, columns n..n+cnt-1); v holds the raw accumulators.
 // Vector path: 2 x 16-byte fp32 accesses / one 16-byte bf16 access per operand.
 // EPI selects which transcendental paths are compiled in: 0 none/ReLU only, 1 + GELU activation,
-// 2 + GELU' multiply, 3 both (erff expands to >100 instructions per element, so lean kernels leave it out)
-template <int EPI>
+// 2 + GELU' multiply, 3 both (erff expands to >100 instructions per element, so lean kernels leave it out);
+// FAST (bf16 compute mode) takes the A&S erf
+template <int EPI, bool FAST = false>
 static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m, int n, float (&v)[8], int cnt, bool vec,
                                           const float* pre_res = nullptr, const float* pre_bias = nullptr) {
     const float* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
@@ -54,7 +55,7 @@ static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m
         if (cpre) st8(cpre + (long long)m * p.ldpre + n);
         if ((EPI & 1) && p.act == SQ_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = sq_gelu<FAST>(v[e]);
         } else if (p.act == SQ_ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -63,7 +64,7 @@ static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m
             const float* gs = gg + (long long)m * p.ldgg + n;
             const f32x4 t0 = *reinterpret_cast<const f32x4*>(gs), t1 = *reinterpret_cast<const f32x4*>(gs + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] *= gelu_erf_grad(t0[e]); v[4 + e] *= gelu_erf_grad(t1[e]); }
+            for (int e = 0; e < 4; ++e) { v[e] *= sq_gelu_grad<FAST>(t0[e]); v[4 + e] *= sq_gelu_grad<FAST>(t1[e]); }
         }
         if (c32) st8(c32 + (long long)m * p.ldc + n);
         if (c16p) st8h(c16p + (long long)m * p.ldc + n);
@@ -77,9 +78,9 @@ static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m
             if (res32) x += res32[(long long)m * p.ldres + ne];
             if (res16) x += bf16_to_f32(res16[(long long)m * p.ldres + ne]);
             if (cpre) cpre[(long long)m * p.ldpre + ne] = x;
-            if ((EPI & 1) && p.act == SQ_ACT_GELU) x = gelu_erf(x);
+            if ((EPI & 1) && p.act == SQ_ACT_GELU) x = sq_gelu<FAST>(x);
             else if (p.act == SQ_ACT_RELU) x = fmaxf(x, 0.f);
-            if ((EPI & 2) && gg) x *= gelu_erf_grad(gg[(long long)m * p.ldgg + ne]);
+            if ((EPI & 2) && gg) x *= sq_gelu_grad<FAST>(gg[(long long)m * p.ldgg + ne]);
             if (c32) c32[(long long)m * p.ldc + ne] = x;
             if (c16p) c16p[(long long)m * p.ldc + ne] = f32_to_bf16(x);
             if (c2) c2[(long long)m * p.ldc2 + ne] = f32_to_bf16(x);
