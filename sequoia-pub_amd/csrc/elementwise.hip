@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 }
 
 // 16 lanes per 64-wide group (4 elements per lane), 4 groups per wave-iteration
+template <bool FAST>
 __global__ __launch_bounds__(256) void ln64_gelu_kernel(const float4* __restrict__ x, const float4* __restrict__ g,
                                                         const float4* __restrict__ b, void* __restrict__ y, int out_bf16,
                                                         uint32_t ngroups, int C16) {
@@ -119,10 +120,10 @@ __global__ __launch_bounds__(256) void ln64_gelu_kernel(const float4* __restrict
         const int c4 = (int)(i4 % (uint32_t)C16);   // float4 column inside the row
         const float4 gg = g[c4], bb = b[c4];
         float4 o;
-        o.x = gelu_erf(a0 * rstd * gg.x + bb.x);
-        o.y = gelu_erf(a1 * rstd * gg.y + bb.y);
-        o.z = gelu_erf(a2 * rstd * gg.z + bb.z);
-        o.w = gelu_erf(a3 * rstd * gg.w + bb.w);
+        o.x = sq_gelu<FAST>(a0 * rstd * gg.x + bb.x);
+        o.y = sq_gelu<FAST>(a1 * rstd * gg.y + bb.y);
+        o.z = sq_gelu<FAST>(a2 * rstd * gg.z + bb.z);
+        o.w = sq_gelu<FAST>(a3 * rstd * gg.w + bb.w);
         if (out_bf16) reinterpret_cast<uint2*>(y)[i4] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
         else reinterpret_cast<float4*>(y)[i4] = o;
     }
@@ -244,7 +245,10 @@ int sq_k_ln64_gelu(const float* x, const float* g, const float* b, void* y, int 
     SQ_REQUIRE(C % 64 == 0, "ln64_gelu: C=%d must be a multiple of 64", C);
     SQ_REQUIRE((size_t)R * (C / 4) < (1ull << 31), "ln64_gelu: tensor too large for 32-bit indexing");
     const uint32_t ngroups = (uint32_t)((size_t)R * (C / 64));
-    hipLaunchKernelGGL(ln64_gelu_kernel, dim3(grid_for((size_t)ngroups * 16, 256)), dim3(256), 0, s, (const float4*)x,
+    // bf16 output: the 7-term erf (sq_common.h); fp32 (parity mode): erff
+    if (out_dtype == SQ_BF16) hipLaunchKernelGGL(ln64_gelu_kernel<true>, dim3(grid_for((size_t)ngroups * 16, 256)), dim3(256), 0, s, (const float4*)x,
+                       (const float4*)g, (const float4*)b, y, out_dtype == SQ_BF16, ngroups, C / 4);
+    else hipLaunchKernelGGL(ln64_gelu_kernel<false>, dim3(grid_for((size_t)ngroups * 16, 256)), dim3(256), 0, s, (const float4*)x,
                        (const float4*)g, (const float4*)b, y, out_dtype == SQ_BF16, ngroups, C / 4);
     SQ_LAUNCH_CHECK();
     return SQ_OK;

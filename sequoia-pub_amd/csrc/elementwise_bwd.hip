@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
 }
 
 // thread owns float4 column(s) (fixed), walks rows; 16 lanes = one 64-wide group
-template <int NCH>
+template <int NCH, bool FAST>
 __global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ b,
                                                             void* __restrict__ dx, int out_bf16, float* __restrict__ ws,
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const float* __restr
             for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
             const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
             a0 *= rstd; a1 *= rstd; a2 *= rstd; a3 *= rstd;                       // xhat
-            const float z0 = d.x * gelu_erf_grad(a0 * gg.x + bb.x), z1 = d.y * gelu_erf_grad(a1 * gg.y + bb.y);
-            const float z2 = d.z * gelu_erf_grad(a2 * gg.z + bb.z), z3 = d.w * gelu_erf_grad(a3 * gg.w + bb.w);
+            const float z0 = d.x * sq_gelu_grad<FAST>(a0 * gg.x + bb.x), z1 = d.y * sq_gelu_grad<FAST>(a1 * gg.y + bb.y);
+            const float z2 = d.z * sq_gelu_grad<FAST>(a2 * gg.z + bb.z), z3 = d.w * sq_gelu_grad<FAST>(a3 * gg.w + bb.w);
             ag[k].x += z0 * a0; ag[k].y += z1 * a1; ag[k].z += z2 * a2; ag[k].w += z3 * a3;
             ab[k].x += z0; ab[k].y += z1; ab[k].z += z2; ab[k].w += z3;
             const float h0 = z0 * gg.x, h1 = z1 * gg.y, h2 = z2 * gg.z, h3 = z3 * gg.w;   // d xhat
@@ -376,9 +376,16 @@ int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const fl
     if (nblk * rpi > LN_BWD_PARTIALS) nblk = LN_BWD_PARTIALS / rpi;
     const dim3 grid(nblk), block(256);
     const int ob = out_dtype == SQ_BF16;
-    if (nch == 1) hipLaunchKernelGGL(ln64_gelu_bwd_kernel<1>, grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
-    else if (nch == 2) hipLaunchKernelGGL(ln64_gelu_bwd_kernel<2>, grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
-    else hipLaunchKernelGGL(ln64_gelu_bwd_kernel<4>, grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+    // bf16 gradients out: the 7-term erf (consistent with the forward kernel); fp32: erff
+    if (ob) {
+        if (nch == 1) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<1, true>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+        else if (nch == 2) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<2, true>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<4, true>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+    } else {
+        if (nch == 1) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<1, false>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+        else if (nch == 2) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<2, false>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<4, false>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+    }
     SQ_LAUNCH_CHECK();
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * C;
     return colsum_impl(ws, SQ_F32, nblk * rpi, 2 * C, 2 * C, cs_ws, dg, s, db, C);
