@@ -21,6 +21,9 @@
 
 #include <cstdio>
 
+bool sq_gemm256_eligible(const GemmArgs& a, int dtype);
+int sq_launch_gemm256(const GemmArgs& a, hipStream_t stream);
+
 namespace {
 
 constexpr uint32_t OOB = 0x80000000u;
@@ -471,7 +474,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return SQ_OK;
 }
 
-int g_force_tile = 0, g_dbg = 0, g_force_split = 0;
+int g_force_tile = 0, g_dbg = 0, g_force_split = 0, g_use256 = -1;
 }
 extern int g_tn_force_split;
 namespace {
@@ -506,7 +509,11 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
         if (s > 1) a.splitk = (int)s;
     }
     if (g_force_split > 0 && a.splitk_ws && a.N % 8 == 0) a.splitk = g_force_split;
-    if (tile == 22) return launch_cfg<T, 2, 2>(a, stream);
+    if constexpr (sizeof(T) == 2) {
+        if (g_use256 < 0) g_use256 = sq_env_flag("SQ_GEMM256") ? 1 : 0;      // opt-in, see gemm256.hip
+        if ((g_force_tile == 44 || (g_force_tile == 0 && g_use256)) && a.splitk == 1 && sq_gemm256_eligible(a, SQ_BF16)) return sq_launch_gemm256(a, stream);
+    }
+    if (tile == 22 || tile == 44) return launch_cfg<T, 2, 2>(a, stream);
     if (tile == 21) return launch_cfg<T, 2, 1>(a, stream);
     if (tile == 12) return launch_cfg<T, 1, 2>(a, stream);
     return launch_cfg<T, 1, 1>(a, stream);
@@ -520,6 +527,7 @@ extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
     else if (key == 2) g_force_split = value;
+    else if (key == 5) g_use256 = value;
     else if (key == 4) g_tn_force_split = value;
     else return SQ_ERR_ARG;
     return SQ_OK;

@@ -39,13 +39,21 @@ def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6)):
             lib.sq_dbg_set(1, dbg)
             fn = lambda: _lib.check(lib.sq_linear(dtype, _lib.ptr(A), K, _lib.ptr(W), K, None, None, 0, 0, 0, _lib.ptr(C), 0, N, M, N, K, _lib.ptr(WS), WS.numel(), _lib.stream_ptr()))
             t = time_fn(fn)
-            print(f"   tile {tile} dbg {dbg}: {t:8.1f} us {flops / t / 1e6:8.1f} TF", flush=True)
+            err = ""
+            if dbg == 0 and M * N <= (1 << 28):
+                ref = torch.matmul(A, W.T).float()
+                err = f"  max rel err vs torch {float((C - ref).abs().max() / ref.abs().max()):.2e}"
+            print(f"   tile {tile} dbg {dbg}: {t:8.1f} us {flops / t / 1e6:8.1f} TF{err}", flush=True)
     lib.sq_dbg_set(0, 0)
     lib.sq_dbg_set(1, 0)
 
 
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        for M, N, K in [(8192, 8192, 8192), (102400, 1024, 1024), (98000, 1024, 256), (98000, 512, 1024), (24500, 2048, 512), (392000, 512, 128)]:
+            probe(M, N, K, _lib.SQ_BF16, tiles=(22, 44), dbgs=(0,))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "resnet":
         for M, N, K in [(39200, 1024, 256), (9800, 2048, 512), (39200, 256, 1024), (156800, 512, 128), (156800, 128, 512),
                         (9800, 512, 2048), (627200, 64, 256), (627200, 256, 64), (39200, 512, 1024)]:
