@@ -334,11 +334,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     _lib.require_gpu()
-    device = torch.device("cuda", local)
+    # SQ_BENCH_SHARE_GPU=1 (debugging aid for 1-GPU boxes): every rank uses cuda:0 and the collectives go through
+    # gloo -- exercises the multi-process control flow (rendezvous, bucketed all-reduce, barriers), not RCCL
+    share = os.environ.get("SQ_BENCH_SHARE_GPU") == "1"
+    device = torch.device("cuda", 0 if share else local)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if share:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
 
     wl = WORKLOADS[args.workload](args, rank, world, device)
     dt = timed_region(wl["step"], args.steps, args.warmup, world, device)
