@@ -51,7 +51,7 @@ def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6)):
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "big":
-        for M, N, K in [(8192, 8192, 8192), (102400, 1024, 1024), (98000, 1024, 256), (98000, 512, 1024), (24500, 2048, 512), (392000, 512, 128)]:
+        for M, N, K in [(8192, 8192, 8192), (102400, 1024, 1024), (98000, 1024, 256), (98000, 512, 1024), (24500, 2048, 512), (392000, 512, 128), (98000, 256, 1024), (392000, 128, 512)]:
             probe(M, N, K, _lib.SQ_BF16, tiles=(22, 44), dbgs=(0,))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "resnet":
