@@ -14,18 +14,18 @@ struct GemmArgs {
     const void* B = nullptr;      // [N, K] (ldb) in T
     void* C = nullptr;            // [M, N] (ldc) f32 or bf16 (out_dtype)
     bf16_t* C2 = nullptr;         // optional bf16 copy of C (ldc2)
-    float* Cpre = nullptr;        // optional f32 copy of the pre-activation value (ldpre)
+    void* Cpre = nullptr;         // optional copy of the pre-activation value (ldpre), f32 or bf16 (pre_dtype)
     const float* bias = nullptr;      // [N]
     const float* rowbias = nullptr;   // [ceil(M / rows_per_group), N] (ldrb)
     const void* res = nullptr;        // [M, N] (ldres) f32 or bf16 (res_dtype)
-    const float* gelu_grad_of = nullptr;  // [M, N] (ldgg): result *= GELU'(gelu_grad_of[m,n]) (backward of an activation)
+    const void* gelu_grad_of = nullptr;   // [M, N] (ldgg), f32 or bf16 (gg_dtype): result *= GELU'(gelu_grad_of[m,n])
     float alpha = 1.0f;               // scales the accumulator before the epilogue terms
     float* colsum_a = nullptr;        // TN only, batch == 1: [M] sums of A's columns over the K contracted rows (bias gradient, unscaled)
     int M = 0, N = 0, K = 0;
     int lda = 0, ldb = 0, ldc = 0, ldc2 = 0, ldpre = 0, ldres = 0, ldrb = 0, ldgg = 0;
     int rows_per_group = 1;
     int act = SQ_ACT_NONE;
-    int out_dtype = SQ_F32, res_dtype = SQ_F32;
+    int out_dtype = SQ_F32, res_dtype = SQ_F32, pre_dtype = SQ_F32, gg_dtype = SQ_F32;
     int batch = 1;
     long long sA = 0, sB = 0, sC = 0, sC2 = 0, sPre = 0, sBias = 0, sRb = 0, sRes = 0, sGg = 0;   // per-batch strides (elements)
     // implicit-GEMM convolution view of A: NHWC [n, H, W, Cin]; K = KH*KW*Cin, tap-major

@@ -308,11 +308,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     // U rows BEFORE that group's first store.
     const float* res32 = (p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
     const float* rowbias = p.rowbias ? p.rowbias + (long long)z * p.sRb : nullptr;
-    const float* gg = p.gelu_grad_of ? p.gelu_grad_of + (long long)z * p.sGg : nullptr;
+    const float* gg = (p.gelu_grad_of && p.gg_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.gelu_grad_of) + (long long)z * p.sGg : nullptr;
+    const bf16_t* gg16 = (p.gelu_grad_of && p.gg_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.gelu_grad_of) + (long long)z * p.sGg : nullptr;
     float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
     bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
     bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
-    float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
+    float* cpre = (p.Cpre && p.pre_dtype == SQ_F32) ? reinterpret_cast<float*>(p.Cpre) + (long long)z * p.sPre : nullptr;
+    bf16_t* cpre16 = (p.Cpre && p.pre_dtype == SQ_BF16) ? reinterpret_cast<bf16_t*>(p.Cpre) + (long long)z * p.sPre : nullptr;
+    const bool has_gg = gg != nullptr || gg16 != nullptr;
     constexpr int U = ITER < 4 ? ITER : 4;
 #pragma unroll
     for (int c0 = 0; c0 < ITER; c0 += U) {
@@ -321,15 +324,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int e = 0; e < 8; ++e) aux[u][e] = 0.f;
-        if ((EPI & 2) && gg) {
+        if ((EPI & 2) && has_gg) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int m = m0 + e_rbase + (c0 + u) * RPI;
                 if (m < p.M) {
-                    const float* src = gg + (long long)m * p.ldgg + e_n;
-                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+                    if (gg16) {
+                        const u32x4 t = *reinterpret_cast<const u32x4*>(gg16 + (long long)m * p.ldgg + e_n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { aux[u][e] = t0[e]; aux[u][4 + e] = t1[e]; }
+                        for (int e = 0; e < 4; ++e) { aux[u][2 * e] = __uint_as_float(t[e] << 16); aux[u][2 * e + 1] = __uint_as_float(t[e] & 0xffff0000u); }
+                    } else {
+                        const float* src = gg + (long long)m * p.ldgg + e_n;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { aux[u][e] = t0[e]; aux[u][4 + e] = t1[e]; }
+                    }
                 }
             }
         } else {
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(rr16[c0 + u][e] << 16); v[2 * e + 1] += __uint_as_float(rr16[c0 + u][e] & 0xffff0000u); }
             }
-            if (!((EPI & 2) && gg)) {
+            if (!((EPI & 2) && has_gg)) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += aux[u][e];
             }
@@ -381,6 +390,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
                 *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
             }
+            if (cpre16)
+                *reinterpret_cast<u32x4*>(cpre16 + (long long)m * p.ldpre + e_n) =
+                    u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             if ((EPI & 1) && p.act == SQ_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = sq_gelu<sizeof(T) == 2>(v[e]);
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if ((EPI & 2) && gg) {
+            if ((EPI & 2) && has_gg) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= sq_gelu_grad<sizeof(T) == 2>(aux[u][e]);
             }
@@ -556,8 +568,8 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
             return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
         };
         auto al8 = [&](const void* ptr, int ld, long long st) { return al(ptr, ld, st, 2); };   // bf16 rows: 16-byte accesses
-        bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, 4) &&
-                  al(a.gelu_grad_of, a.ldgg, a.sGg, 4) && al8(a.C2, a.ldc2, a.sC2);
+        bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, a.pre_dtype == SQ_F32 ? 4 : 2) &&
+                  al(a.gelu_grad_of, a.ldgg, a.sGg, a.gg_dtype == SQ_F32 ? 4 : 2) && al8(a.C2, a.ldc2, a.sC2);
         ok = ok && (a.out_dtype == SQ_F32 ? al(a.C, a.ldc, a.sC, 4) : al8(a.C, a.ldc, a.sC));
         ok = ok && (a.res_dtype == SQ_F32 ? al(a.res, a.ldres, a.sRes, 4) : al8(a.res, a.ldres, a.sRes));
         av.vec_epi = ok ? 1 : 0;
@@ -571,8 +583,8 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
         // every operand read once, every output written once (residual / GELU' source / extra copies included)
         double mn_bytes = a.out_dtype == SQ_BF16 ? 2.0 : 4.0;
         if (a.res) mn_bytes += a.res_dtype == SQ_BF16 ? 2.0 : 4.0;
-        if (a.gelu_grad_of) mn_bytes += 4.0;
-        if (a.Cpre) mn_bytes += 4.0;
+        if (a.gelu_grad_of) mn_bytes += a.gg_dtype == SQ_F32 ? 4.0 : 2.0;
+        if (a.Cpre) mn_bytes += a.pre_dtype == SQ_F32 ? 4.0 : 2.0;
         if (a.C2) mn_bytes += 2.0;
         const double bytes = (a_elems * es + (double)a.N * a.K * es) * a.batch + (double)a.M * a.N * a.batch * mn_bytes;
         char name[96];

@@ -17,8 +17,10 @@ static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m
     float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
     bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
     bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
-    float* cpre = p.Cpre ? p.Cpre + (long long)z * p.sPre : nullptr;
-    const float* gg = p.gelu_grad_of ? p.gelu_grad_of + (long long)z * p.sGg : nullptr;
+    float* cpre = (p.Cpre && p.pre_dtype == SQ_F32) ? reinterpret_cast<float*>(p.Cpre) + (long long)z * p.sPre : nullptr;
+    bf16_t* cpre16 = (p.Cpre && p.pre_dtype == SQ_BF16) ? reinterpret_cast<bf16_t*>(p.Cpre) + (long long)z * p.sPre : nullptr;
+    const float* gg = (p.gelu_grad_of && p.gg_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.gelu_grad_of) + (long long)z * p.sGg : nullptr;
+    const bf16_t* gg16 = (p.gelu_grad_of && p.gg_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.gelu_grad_of) + (long long)z * p.sGg : nullptr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
     const long long rb_row = rowbias ? (long long)(m / p.rows_per_group) * p.ldrb : 0;
@@ -53,6 +55,7 @@ static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m
             for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(t[e] << 16); v[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
         }
         if (cpre) st8(cpre + (long long)m * p.ldpre + n);
+        if (cpre16) st8h(cpre16 + (long long)m * p.ldpre + n);
         if ((EPI & 1) && p.act == SQ_ACT_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = sq_gelu<FAST>(v[e]);
@@ -66,6 +69,14 @@ static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] *= sq_gelu_grad<FAST>(t0[e]); v[4 + e] *= sq_gelu_grad<FAST>(t1[e]); }
         }
+        if ((EPI & 2) && gg16) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(gg16 + (long long)m * p.ldgg + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] *= sq_gelu_grad<FAST>(__uint_as_float(t[e] << 16));
+                v[2 * e + 1] *= sq_gelu_grad<FAST>(__uint_as_float(t[e] & 0xffff0000u));
+            }
+        }
         if (c32) st8(c32 + (long long)m * p.ldc + n);
         if (c16p) st8h(c16p + (long long)m * p.ldc + n);
         if (c2) st8h(c2 + (long long)m * p.ldc2 + n);
@@ -78,9 +89,11 @@ static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m
             if (res32) x += res32[(long long)m * p.ldres + ne];
             if (res16) x += bf16_to_f32(res16[(long long)m * p.ldres + ne]);
             if (cpre) cpre[(long long)m * p.ldpre + ne] = x;
+            if (cpre16) cpre16[(long long)m * p.ldpre + ne] = f32_to_bf16(x);
             if ((EPI & 1) && p.act == SQ_ACT_GELU) x = sq_gelu<FAST>(x);
             else if (p.act == SQ_ACT_RELU) x = fmaxf(x, 0.f);
             if ((EPI & 2) && gg) x *= sq_gelu_grad<FAST>(gg[(long long)m * p.ldgg + ne]);
+            if ((EPI & 2) && gg16) x *= sq_gelu_grad<FAST>(bf16_to_f32(gg16[(long long)m * p.ldgg + ne]));
             if (c32) c32[(long long)m * p.ldc + ne] = x;
             if (c16p) c16p[(long long)m * p.ldc + ne] = f32_to_bf16(x);
             if (c2) c2[(long long)m * p.ldc2 + ne] = f32_to_bf16(x);

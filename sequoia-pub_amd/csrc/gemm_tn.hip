@@ -305,8 +305,8 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
         auto al = [](const void* ptr, int ld, long long st, int elem) {
             return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
         };
-        bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, 4) &&
-                  al(a.gelu_grad_of, a.ldgg, a.sGg, 4) && al(a.C2, a.ldc2, a.sC2, 2);
+        bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, a.pre_dtype == SQ_F32 ? 4 : 2) &&
+                  al(a.gelu_grad_of, a.ldgg, a.sGg, a.gg_dtype == SQ_F32 ? 4 : 2) && al(a.C2, a.ldc2, a.sC2, 2);
         ok = ok && al(a.C, a.ldc, a.sC, a.out_dtype == SQ_F32 ? 4 : 2) && al(a.res, a.ldres, a.sRes, a.res_dtype == SQ_F32 ? 4 : 2);
         a.vec_epi = ok ? 1 : 0;
     }

@@ -29,10 +29,10 @@ struct VisBufs {
     float* Sm[SQ_MAX_DEPTH];            // [B, HD] f32  s(mean x)+b (pre-LN)
     void* Ts[SQ_MAX_DEPTH];             // [B, HD] T    GELU(LN64(Sm))
     float* Cs[SQ_MAX_DEPTH];            // [B, HD] f32  summary half of the combiner + bias
-    float* P[SQ_MAX_DEPTH];             // [M, HD] f32  combiner pre-activation (saved only when training)
+    void* P[SQ_MAX_DEPTH];              // [M, HD] T    combiner pre-activation (saved only when training)
     void* O[SQ_MAX_DEPTH];              // [M, HD] T    GELU(P)
     void* Y[SQ_MAX_DEPTH];              // [M, D] T     LayerNorm(X1)
-    float* U[SQ_MAX_DEPTH];             // [M, D] f32   FF pre-activation (saved only when training)
+    void* U[SQ_MAX_DEPTH];              // [M, D] T     FF pre-activation (saved only when training)
     void* H1[SQ_MAX_DEPTH];             // [M, D] T     GELU(U)
     float* skws; size_t skws_bytes;     // split-K scratch for the skinny (M = B) GEMMs
     float* xm;                          // [B, D] f32 token mean of the last layer output
@@ -41,3 +41,9 @@ struct VisBufs {
 };
 
 void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base, VisBufs* out);
+
+// dtype of the saved GELU pre-activations (U, P): the operand dtype; SQ_F32_PREACT=1 keeps fp32 (A/B knob)
+inline int sq_vis_preact_dtype(int dtype) {
+    static const int force32 = sq_env_flag("SQ_F32_PREACT") ? 1 : 0;
+    return force32 ? SQ_F32 : dtype;
+}

@@ -21,6 +21,7 @@
 void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base, VisBufs* o) {
     Arena a{base, 0};
     const size_t es = sq_dtype_size(dtype);
+    const size_t pes = sq_dtype_size(sq_vis_preact_dtype(dtype));
     const size_t M = (size_t)B * c.num_clusters, D = c.input_dim, HD = (size_t)c.nheads * SQ_HEAD_DIM;
     const int L = save ? c.depth : 1;
     o->nsave = L;
@@ -46,10 +47,10 @@ void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base,
             o->Sm[l] = (float*)a.take((size_t)B * HD * 4);
             o->Ts[l] = a.take((size_t)B * HD * es);
             o->Cs[l] = (float*)a.take((size_t)B * HD * 4);
-            o->P[l] = save ? (float*)a.take(M * HD * 4) : nullptr;
+            o->P[l] = save ? a.take(M * HD * pes) : nullptr;     // bf16 mode: the GELU' source is kept in bf16 (half the traffic)
             o->O[l] = a.take(M * HD * es);
             o->Y[l] = a.take(M * D * es);
-            o->U[l] = save ? (float*)a.take(M * D * 4) : nullptr;
+            o->U[l] = save ? a.take(M * D * pes) : nullptr;
             o->H1[l] = a.take(M * D * es);
         } else {
             o->X1[l] = o->X1[0]; o->X1_lp[l] = o->X1_lp[0]; o->Xbar32[l] = o->Xbar32[0]; o->Xbar[l] = o->Xbar[0];
@@ -190,7 +191,7 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
             GemmArgs g; g.A = w.Lf[s]; g.lda = HD; g.a_bytes = (size_t)M * HD * es; g.sA = SQ_HEAD_DIM;
             g.B = W(L.c_w); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
             g.rowbias = w.Cs[s]; g.ldrb = HD; g.sRb = SQ_HEAD_DIM; g.rows_per_group = N;
-            g.act = SQ_ACT_GELU; g.Cpre = w.P[s]; g.ldpre = HD; g.sPre = SQ_HEAD_DIM;
+            g.act = SQ_ACT_GELU; g.Cpre = w.P[s]; g.pre_dtype = sq_vis_preact_dtype(dtype); g.ldpre = HD; g.sPre = SQ_HEAD_DIM;
             g.C = w.O[s]; g.out_dtype = dtype; g.ldc = HD; g.sC = SQ_HEAD_DIM;
             g.M = M; g.N = SQ_HEAD_DIM; g.K = SQ_HEAD_DIM; g.batch = H;
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
@@ -205,7 +206,7 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
         {   // H1 = GELU(Y W1^T + b1)
             GemmArgs g; g.A = w.Y[s]; g.lda = D; g.a_bytes = (size_t)M * D * es;
             g.B = W(L.ff1_w); g.ldb = D; g.b_bytes = Wrem(L.ff1_w); g.bias = Pf(L.ff1_b);
-            g.act = SQ_ACT_GELU; g.Cpre = w.U[s]; g.ldpre = D;
+            g.act = SQ_ACT_GELU; g.Cpre = w.U[s]; g.pre_dtype = sq_vis_preact_dtype(dtype); g.ldpre = D;
             g.C = w.H1[s]; g.out_dtype = dtype; g.ldc = D; g.M = M; g.N = D; g.K = D;
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }

@@ -272,7 +272,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         { GemmArgs g = gemm_tn(lg.dXin_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); g.colsum_a = Gp_(L.ff2_b); RUN(run_tn(g)); }
         {   // dU = (dX2 . W2) * GELU'(U)
             GemmArgs g = gemm(lg.dXin_lp, D, b.wt[l].ff2, D, nullptr, D, M, D, D);
-            g.C = lg.dU; g.out_dtype = dtype; g.gelu_grad_of = w.U[l]; g.ldgg = D;
+            g.C = lg.dU; g.out_dtype = dtype; g.gelu_grad_of = w.U[l]; g.gg_dtype = sq_vis_preact_dtype(dtype); g.ldgg = D;
             RUN(sq_launch_gemm(g, dtype, st));
         }
         RUN(ready());
@@ -288,7 +288,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         { GemmArgs g = gemm_tn(lg.dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); g.colsum_a = Gp_(L.proj_b); RUN(run_tn(g)); }
         {   // dP = (dX1 . Wp) * GELU'(P)
             GemmArgs g = gemm(lg.dX1_lp, D, b.wt[l].proj, D, nullptr, HD, M, HD, D);
-            g.C = lg.dP; g.out_dtype = dtype; g.gelu_grad_of = w.P[l]; g.ldgg = HD;
+            g.C = lg.dP; g.out_dtype = dtype; g.gelu_grad_of = w.P[l]; g.gg_dtype = sq_vis_preact_dtype(dtype); g.ldgg = HD;
             RUN(sq_launch_gemm(g, dtype, st));
         }
         // ---------------- combiner: P_h = Lf_h Wc_h[:, :64]^T + Ts_h Wc_h[:, 64:]^T + bc_h ----------------
