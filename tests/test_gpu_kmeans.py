@@ -98,3 +98,19 @@ def test_duplicate_points_and_empty_clusters():
 def test_too_few_samples_raises():
     with pytest.raises(ValueError):
         KMeans(n_clusters=100).fit(np.zeros((50, 16), np.float32))
+
+
+def test_maximum_patch_count_and_minimum():
+    """The reference caps slides at max_patch_number = 4000 patches (compute_features_hdf5.py:33): the largest slide
+    the kernels accept (n = 4096) and the smallest legal one (n = n_clusters) against the oracle; n = 4097 is refused."""
+    _lib.require_gpu()
+    X = synth.features_gmm(77, 4096, 2048)
+    r = kmeans_fit_batch(torch.from_numpy(X).cuda()[None], 100)
+    o = ko.kmeans_fit(X)
+    assert np.array_equal(r["labels"][0].cpu().numpy(), o["labels"]) and int(r["n_iter"][0]) == o["n_iter"]
+    assert np.array_equal(r["cluster_features"][0].cpu().numpy(), ko.cluster_means(X, o["labels"]))
+    Xs = synth.features_gmm(78, 100, 64)
+    rs = kmeans_fit_batch(torch.from_numpy(Xs).cuda()[None], 100)
+    assert sorted(rs["labels"][0].cpu().tolist()) == list(range(100))          # every point its own cluster
+    with pytest.raises(_lib.SequoiaHipError):
+        kmeans_fit_batch(torch.zeros(1, 4097, 64).cuda(), 100)
