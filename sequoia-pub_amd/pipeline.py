@@ -46,6 +46,9 @@ class SlidePipeline:
             self._side = torch.cuda.Stream(device=dev)
         side = self._side
         feats, cfs, labels = [], [], []
+        if len(slides_u8) == 0:
+            z = torch.empty(0, self.vis.cfg.num_outputs, device=dev)
+            return dict(pred=z, cluster_features=torch.empty(0, self.n_clusters, self.vis._dim(), device=dev), labels=[], features=[])
 
         def cluster_on_side(f, ev):
             side.wait_event(ev)

@@ -96,3 +96,18 @@ def test_head_replacement_and_checkpoint_round_trip(tmp_path):
     loss.backward()
     opt.step()
     assert not torch.equal(m.state_dict()["linear_head.1.weight"].cpu(), sd2["linear_head.1.weight"])
+
+
+def test_empty_inputs():
+    """No patches / no slides: empty results, no launches, no exceptions; a slide with fewer patches than clusters is
+    the caller's error, as with scikit-learn (kmean_features.py catches it per slide and moves on)."""
+    _lib.require_gpu()
+    rn = resnet50(pretrained=False, compute_dtype="bf16").to("cuda:0").eval()
+    out = rn.extract_patches_u8(torch.empty(0, 224, 224, 3, dtype=torch.uint8).cuda())
+    assert out.shape == (0, 2048)
+    vis, _ = _vis(input_dim=2048)
+    pipe = SlidePipeline(rn, vis)
+    r = pipe([])
+    assert r["pred"].shape == (0, 60) and r["labels"] == []
+    with pytest.raises(Exception):
+        pipe([torch.from_numpy(synth.patches_u8(1, 20, 224)).cuda()])      # 20 patches < 100 clusters
