@@ -49,9 +49,11 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def timed_region(step_fn, steps, warmup, world, device):
+def timed_region(step_fn, steps, warmup, world, device, flush_fn=None):
     for _ in range(warmup):
         step_fn()
+    if flush_fn:
+        flush_fn()
     barrier_sync(world)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -59,6 +61,8 @@ def timed_region(step_fn, steps, warmup, world, device):
         if os.environ.get("SQ_BENCH_STEPTIMES"):       # debugging aid: per-step wall time (adds a sync per step)
             torch.cuda.synchronize()
             print(f"step done at {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
+    if flush_fn:                      # streaming workloads: work still in flight belongs to the timed region
+        flush_fn()
     barrier_sync(world)
     dt = time.perf_counter() - t0
     if world > 1:
@@ -238,6 +242,9 @@ def workload_pipeline(args, rank, world, device):
     cfg = dict(VIS_CFG, input_dim=2048)
     vis = ViS(**cfg, num_clusters=100, device=str(device), compute_dtype=args.dtype).to(device).eval()
     pipe = SlidePipeline(rn, vis, sub_batch=args.sub_batch)
+    # streaming form (default): the last slide's k-Means + ViS forward of a step run under the next step's first ResNet;
+    # whatever is still in flight is flushed inside the timed region.  --no-stream: every step completes on its own.
+    run = pipe if args.no_stream else pipe.submit
     host = [torch.from_numpy(synth.patches_u8(rank * nslides + i, npatch, 224)) for i in range(nslides)]
     if args.from_host:
         # PCIe-inclusive variant (reported in DESIGN.md, never `value` of the default run): slides live in pinned host
@@ -256,12 +263,12 @@ def workload_pipeline(args, rank, world, device):
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)
                     evs.append(ev)
-            pipe(list(zip(staging, evs)))    # the pipeline waits for slide i's upload right before embedding it
+            run(list(zip(staging, evs)))     # the pipeline waits for slide i's upload right before embedding it
     else:
         slides = [h.to(device) for h in host]
 
         def step():
-            pipe(slides)
+            run(slides)
 
     def cpu_baseline():
         from oracle import kmeans_oracle, resnet_oracle, vis_oracle
@@ -284,7 +291,7 @@ def workload_pipeline(args, rank, world, device):
                 "sample": f"oracle ResNet-50 on {reps} x 32 patches (batched; {rate:.1f} patches/s) extrapolated to "
                           f"{npatch} patches + one oracle k-Means + ViS forward ({t_rest:.2f} s)"}
 
-    return dict(step=step, slides_per_step=nslides, cpu_baseline=cpu_baseline,
+    return dict(step=step, flush=None if args.no_stream else pipe.flush, slides_per_step=nslides, cpu_baseline=cpu_baseline,
                 config={"workload": "pipeline: 1000 x 224x224 uint8 patches/slide -> ResNet-50 embed -> k-Means(100) -> "
                                     "ViS(D=2048, depth 6, 16 heads, G=20820) forward (BASELINE config 3), " +
                                     ("patches uploaded from pinned host memory every step" if args.from_host else "patches resident in HBM"),
@@ -345,6 +352,7 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=500, help="pipeline workload: patches per ResNet launch group")
     ap.add_argument("--grid", type=int, nargs=2, default=[250, 200], help="spatial workload: tile grid")
     ap.add_argument("--batch-windows", type=int, default=1024, help="spatial workload: windows per ViS forward")
+    ap.add_argument("--no-stream", action="store_true", help="pipeline workload: finish every step's slides before the next step starts")
     ap.add_argument("--from-host", action="store_true", help="pipeline workload: upload the patches from pinned host memory every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -366,11 +374,13 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)
 
     wl = WORKLOADS[args.workload](args, rank, world, device)
-    dt = timed_region(wl["step"], args.steps, args.warmup, world, device)
+    dt = timed_region(wl["step"], args.steps, args.warmup, world, device, wl.get("flush"))
     slides = wl["slides_per_step"] * world * args.steps
     value = slides / dt
 
     roof, recs = roofline_from_profile(wl["step"], min(args.steps, 5), args.dtype, args.workload)
+    if wl.get("flush"):
+        wl["flush"]()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = wl["cpu_baseline"]()

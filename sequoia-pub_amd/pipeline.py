@@ -78,3 +78,73 @@ class SlidePipeline:
         cf = torch.cat(cfs)
         pred = self.vis(cf)
         return dict(pred=pred, cluster_features=cf, labels=labels, features=feats)
+
+    # ---- streaming form: throughput over latency -------------------------------------------------------------
+    @torch.no_grad()
+    def submit(self, slides_u8):
+        """Streaming form of __call__ for a long list of slides fed in groups: the clustering and the aggregator
+        forward of the LAST slide of a group are not waited for -- they run beside the first ResNet of the next
+        group -- so no group has an exposed tail.  Returns the results that became complete (a dict like __call__'s,
+        for the slides finished so far, possibly of the previous group), or None.  Call flush() after the last group."""
+        dev = self.vis.flat.device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
+        st = self.__dict__.setdefault("_stream_state", dict(pending=None, done=[]))
+
+        def cluster_on_side(f, ev):
+            side.wait_event(ev)
+            f.record_stream(side)
+            with torch.cuda.stream(side):
+                cf, lab = self.cluster(f.unsqueeze(0))
+                fin = torch.cuda.Event()
+                fin.record(side)
+            cf.record_stream(main)
+            lab.record_stream(main)
+            st["done"].append((f, cf, lab[0], fin))
+
+        for p in slides_u8:
+            if isinstance(p, tuple):
+                p, uploaded = p
+                main.wait_event(uploaded)
+            f = self.embed(p)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            if st["pending"] is not None:
+                cluster_on_side(*st["pending"])
+            st["pending"] = (f, ev)
+        return self._collect(main)
+
+    def _collect(self, main):
+        st = self._stream_state
+        if not st["done"]:
+            return None
+        done, st["done"] = st["done"], []
+        main.wait_event(done[-1][3])               # the side stream is in order: the last event covers all of them
+        cf = torch.cat([d[1] for d in done])
+        pred = self.vis(cf)
+        return dict(pred=pred, cluster_features=cf, labels=[d[2] for d in done], features=[d[0] for d in done])
+
+    @torch.no_grad()
+    def flush(self):
+        """Finish the slide still in flight after the last submit(); returns its results (or None)."""
+        st = self.__dict__.get("_stream_state")
+        if not st:
+            return None
+        dev = self.vis.flat.device
+        main = torch.cuda.current_stream(dev)
+        if st["pending"] is not None:
+            f, ev = st["pending"]
+            st["pending"] = None
+            side = self._side
+            side.wait_event(ev)
+            f.record_stream(side)
+            with torch.cuda.stream(side):
+                cf, lab = self.cluster(f.unsqueeze(0))
+                fin = torch.cuda.Event()
+                fin.record(side)
+            cf.record_stream(main)
+            lab.record_stream(main)
+            st["done"].append((f, cf, lab[0], fin))
+        return self._collect(main)

