@@ -19,6 +19,10 @@ struct GemmArgs {
     const float* rowbias = nullptr;   // [ceil(M / rows_per_group), N] (ldrb)
     const void* res = nullptr;        // [M, N] (ldres) f32 or bf16 (res_dtype)
     const void* gelu_grad_of = nullptr;   // [M, N] (ldgg), f32 or bf16 (gg_dtype): result *= GELU'(gelu_grad_of[m,n])
+    // per-head LayerNorm(64) + affine, applied after bias / residual (and after the Cpre copy), before the activation:
+    // [N] gain and bias; needs N % 64 == 0, the 16-byte epilogue path and no split-K (else the launcher refuses)
+    const float* ln64_g = nullptr;
+    const float* ln64_b = nullptr;
     float alpha = 1.0f;               // scales the accumulator before the epilogue terms
     float* colsum_a = nullptr;        // TN only, batch == 1: [M] sums of A's columns over the K contracted rows (bias gradient, unscaled)
     int M = 0, N = 0, K = 0;

@@ -147,6 +147,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
             rr16[u] = m < p.M ? *reinterpret_cast<const u32x4*>(r16 + (long long)m * p.ldres + e_n) : u32x4{0, 0, 0, 0};
         }
     }
+    float lng[8], lnb[8];
+    if constexpr ((EPI & 4) != 0) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln64_g + e_n), g1 = *reinterpret_cast<const f32x4*>(p.ln64_g + e_n + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln64_b + e_n), b1 = *reinterpret_cast<const f32x4*>(p.ln64_b + e_n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lng[e] = g0[e]; lng[4 + e] = g1[e]; lnb[e] = b0[e]; lnb[4 + e] = b1[e]; }
+    }
     const bool pre_b = e_vec && p.bias != nullptr;
     if (pre_b) {
         const float* bsrc = p.bias + (long long)z * p.sBias + e_n;
@@ -393,6 +400,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
             if (cpre16)
                 *reinterpret_cast<u32x4*>(cpre16 + (long long)m * p.ldpre + e_n) =
                     u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            if constexpr ((EPI & 4) != 0) {
+                // LayerNorm over the 64-column head group this thread's 8 columns belong to: the group is 8
+                // consecutive lanes (two-pass mean / variance as nn.LayerNorm, eps 1e-5)
+                float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                const float mean = sm * (1.0f / 64.0f);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * lng[e] + lnb[e];
+            }
             if ((EPI & 1) && p.act == SQ_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = sq_gelu<sizeof(T) == 2>(v[e]);
@@ -461,6 +482,9 @@ template <typename T, int WTM, int WTN, bool CONV>
 int launch_epi(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
     const dim3 block(256);
     if (a.splitk > 1) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, CONV, 0>), grid, block, lds, stream, a);   // partials only
+    else if (a.ln64_g) {
+        if constexpr (!CONV) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, false, 5>), grid, block, lds, stream, a);
+    }
     else if (a.gelu_grad_of) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, CONV, 2>), grid, block, lds, stream, a);
     else if (a.act == SQ_ACT_GELU) hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, CONV, 1>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<T, WTM, WTN, CONV, 0>), grid, block, lds, stream, a);
@@ -591,6 +615,12 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
         snprintf(name, sizeof(name), "%s_%s_M%d_N%d_K%d_b%d", a.conv ? "conv" : "gemm", dtype == SQ_BF16 ? "bf16" : "f32",
                  a.M, a.N, a.K, a.batch);
         prof = sq_prof_begin(name, flops, bytes, stream);
+    }
+    if (av.ln64_g) {
+        SQ_REQUIRE(av.ln64_b && !av.conv && av.N % 64 == 0 && av.vec_epi && !av.gelu_grad_of && ((uintptr_t)av.ln64_g & 15) == 0 &&
+                   ((uintptr_t)av.ln64_b & 15) == 0,
+                   "gemm: the fused LayerNorm(64) epilogue needs N %% 64 == 0 (N=%d), 16-byte aligned operands and a plain A", av.N);
+        av.splitk_ws = nullptr;            // the whole row group must be in one block: no K-slices
     }
     const int rc = dtype == SQ_BF16 ? launch_t<bf16_t>(av, stream) : launch_t<float>(av, stream);
     if (prof >= 0) sq_prof_end(prof, stream);

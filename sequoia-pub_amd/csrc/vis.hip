@@ -179,13 +179,15 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
             if (int e = sq_launch_gemm(g, dtype, s2)) return e;
         }
         if (fs) { ev_cs = fs->events[ev_next++]; SQ_HIP_CHECK(hipEventRecord(ev_cs, s2)); }
-        {   // F = X Wf^T + bf
+        {   // Lf = GELU(LN64(F)),  F = X Wf^T + bf: LayerNorm + GELU in the epilogue (a head's 64 columns sit in 8
+            // lanes of the staged tile); F itself is only written when the backward pass will need it
             GemmArgs g; g.A = Xin_t; g.lda = D; g.a_bytes = (size_t)M * D * es;
             g.B = W(L.f_w); g.ldb = D; g.b_bytes = Wrem(L.f_w); g.bias = Pf(L.f_b);
-            g.C = w.F[s]; g.ldc = HD; g.M = M; g.N = HD; g.K = D;
+            g.ln64_g = Pf(L.lnf_g); g.ln64_b = Pf(L.lnf_b); g.act = SQ_ACT_GELU;
+            if (save) { g.Cpre = w.F[s]; g.pre_dtype = SQ_F32; g.ldpre = HD; }
+            g.C = w.Lf[s]; g.out_dtype = dtype; g.ldc = HD; g.M = M; g.N = HD; g.K = D;
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
-        if (int e = sq_k_ln64_gelu(w.F[s], Pf(L.lnf_g), Pf(L.lnf_b), w.Lf[s], dtype, M, HD, st)) return e;
         if (ev_cs) SQ_HIP_CHECK(hipStreamWaitEvent(st, ev_cs, 0));
         {   // O[m, h] = GELU(Lf[m, h] . Wc_h[:, 0:64]^T + Cs[slide(m), h])
             GemmArgs g; g.A = w.Lf[s]; g.lda = HD; g.a_bytes = (size_t)M * HD * es; g.sA = SQ_HEAD_DIM;
