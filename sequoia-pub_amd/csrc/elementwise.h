@@ -36,6 +36,13 @@ int sq_k_transpose_multi(const sq_transpose_jobs& jobs, int elem_size, hipStream
 int sq_k_cast_pad(const float* src, int lds_, void* dst, int dst_dtype, int ldd, int R, int C, hipStream_t s);
 
 // ---- backward helpers -------------------------------------------------------------------------
+// Deferred column sums: the LayerNorm backward kernels leave <= 512 partial [dg | db] rows; instead of one small
+// reduction launch each, a pass can collect them as jobs and finish a whole layer's worth with ONE launch.
+#define SQ_MAX_COLSUM_JOBS 8
+struct sq_colsum_job { const float* x; float* out; float* out2; int R, C, ld, split, blk0; };
+struct sq_colsum_jobs { sq_colsum_job job[SQ_MAX_COLSUM_JOBS]; int n = 0, blocks = 0; };
+int sq_colsum_jobs_add(sq_colsum_jobs* jobs, const float* x, int R, int C, int ld, float* out, float* out2, int split);
+int sq_k_colsum_multi(const sq_colsum_jobs& jobs, hipStream_t s);
 // out[c] = sum_r x[r, c]   (x f32 or bf16, leading dim ld); ws: >= colsum_ws_floats(C) floats
 size_t sq_colsum_ws_floats(int C);
 int sq_k_colsum(const void* x, int dtype, int R, int C, int ld, float* ws, float* out, hipStream_t s);
@@ -48,7 +55,7 @@ int sq_k_batch_sum(const float* x, float* out, int B, int ND, hipStream_t s);
 // LayerNorm_D backward: dx = dres + dLN(dy; x, g);  dg/db = column sums.  ws >= ln_bwd_ws_floats(D) floats
 size_t sq_ln_bwd_ws_floats(int D);
 int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const float* dres, float* dx, bf16_t* dx_lp,
-                     float* dg, float* db, float* ws, int R, int D, hipStream_t s);
+                     float* dg, float* db, float* ws, int R, int D, hipStream_t s, sq_colsum_jobs* defer = nullptr);
 // backward of y = GELU(LN64(x)*g + b): dx (f32 or bf16 by out_dtype), dg/db [C].  ws >= ln_bwd_ws_floats(C)
 int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const float* b, void* dx, int out_dtype,
-                       float* dg, float* db, float* ws, int R, int C, hipStream_t s);
+                       float* dg, float* db, float* ws, int R, int C, hipStream_t s, sq_colsum_jobs* defer = nullptr);

@@ -71,6 +71,33 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restri
     }
 }
 
+// the same for several matrices in one launch (block -> job by block prefix)
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const sq_colsum_jobs jobs) {
+    __shared__ float red[16][17];
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].blk0) ++j;
+    const sq_colsum_job& J = jobs.job[j];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = ((int)blockIdx.x - J.blk0) * 16 + tx;
+    const float* x = J.x;
+    const int R = J.R, C = J.C, ld = J.ld;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int r = ty;
+        for (; r + 16 < R; r += 32) { a0 += x[(size_t)r * ld + c]; a1 += x[(size_t)(r + 16) * ld + c]; }
+        if (r < R) a0 += x[(size_t)r * ld + c];
+    }
+    red[ty][tx] = a0 + a1;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) v += (red[k][tx] + red[k + 1][tx]) + (red[k + 2][tx] + red[k + 3][tx]);
+        if (J.out2 && c >= J.split) J.out2[c - J.split] = v;
+        else J.out[c] = v;
+    }
+}
+
 // out[g, c] = scale * sum_n x[g*N + n, c]: thread = (g, 4-column chunk, quarter of the rows); the four
 // quarters are combined through LDS in a fixed order
 template <typename T>
@@ -311,6 +338,21 @@ int colsum_impl(const void* x, int dtype, int R, int C, int ld, float* ws, float
 
 size_t sq_colsum_ws_floats(int C) { return (size_t)COLSUM_SPLITS * C; }
 
+int sq_colsum_jobs_add(sq_colsum_jobs* jobs, const float* x, int R, int C, int ld, float* out, float* out2, int split) {
+    SQ_REQUIRE(jobs->n < SQ_MAX_COLSUM_JOBS && R > 0 && R <= 512 && C > 0 && ld >= C, "colsum_multi: job %d R=%d C=%d", jobs->n, R, C);
+    sq_colsum_job& J = jobs->job[jobs->n++];
+    J.x = x; J.out = out; J.out2 = out2; J.R = R; J.C = C; J.ld = ld; J.split = split; J.blk0 = jobs->blocks;
+    jobs->blocks += (C + 15) / 16;
+    return SQ_OK;
+}
+
+int sq_k_colsum_multi(const sq_colsum_jobs& jobs, hipStream_t s) {
+    if (jobs.n == 0) return SQ_OK;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(jobs.blocks), dim3(256), 0, s, jobs);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
 int sq_k_colsum(const void* x, int dtype, int R, int C, int ld, float* ws, float* out, hipStream_t s) {
     SQ_REQUIRE(R > 0 && C > 0 && ld >= C, "colsum: R=%d C=%d ld=%d", R, C, ld);
     return colsum_impl(x, dtype, R, C, ld, ws, out, s);
@@ -351,7 +393,7 @@ int sq_k_batch_sum(const float* x, float* out, int B, int ND, hipStream_t s) {
 size_t sq_ln_bwd_ws_floats(int D) { return (size_t)LN_BWD_PARTIALS * 2 * D + sq_colsum_ws_floats(2 * D); }
 
 int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const float* dres, float* dx, bf16_t* dx_lp, float* dg,
-                     float* db, float* ws, int R, int D, hipStream_t s) {
+                     float* db, float* ws, int R, int D, hipStream_t s, sq_colsum_jobs* defer) {
     SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows_bwd: D=%d", D);
     int nblk = (R + 3) / 4;
     if (nblk > LN_BWD_PARTIALS) nblk = LN_BWD_PARTIALS;
@@ -362,11 +404,12 @@ int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const floa
     SQ_LAUNCH_CHECK();
     // partial rows are [dg | db] of length 2D: one column-sum over nblk*4 partial rows, then split
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * D;
+    if (defer) return sq_colsum_jobs_add(defer, ws, nblk, 2 * D, 2 * D, dg, db, D);
     return colsum_impl(ws, SQ_F32, nblk, 2 * D, 2 * D, cs_ws, dg, s, db, D);
 }
 
 int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const float* b, void* dx, int out_dtype, float* dg,
-                       float* db, float* ws, int R, int C, hipStream_t s) {
+                       float* db, float* ws, int R, int C, hipStream_t s, sq_colsum_jobs* defer) {
     const int C16 = C / 4;
     SQ_REQUIRE(C % 64 == 0 && ((C16 <= 256 && 256 % C16 == 0) || C16 == 512 || C16 == 1024),
                "ln64_gelu_bwd: C=%d (nheads must be a power of two <= 64 for the training path)", C);
@@ -388,5 +431,6 @@ int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const fl
     }
     SQ_LAUNCH_CHECK();
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * C;
+    if (defer && nblk * rpi <= 512) return sq_colsum_jobs_add(defer, ws, nblk * rpi, 2 * C, 2 * C, dg, db, C);
     return colsum_impl(ws, SQ_F32, nblk * rpi, 2 * C, 2 * C, cs_ws, dg, s, db, C);
 }

@@ -40,6 +40,7 @@ struct BwdBufs {
     void* dout_lp;                   // [B, Gp] T
     float* dxn; float* dxm;          // [B, D]
     float* red_ws;                   // reduction scratch
+    float* part_ws[3];               // partial [dg | db] rows of a layer's three LayerNorms (one reduction launch per layer)
     float* skws; size_t skws_bytes;  // split-K scratch (dW products have K = tokens and few output tiles)
     float* skws_side;                // the same for the second stream
     float* red_ws2; float* skws2; size_t skws2_bytes;   // scratch of the summary-branch stream
@@ -88,6 +89,7 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
     const size_t cs = sq_colsum_ws_floats((int)(G > W ? G : W));
     if (cs > red) red = cs;
     o->red_ws = (float*)a.take(red * 4);
+    for (int i = 0; i < 3; ++i) o->part_ws[i] = (float*)a.take(red * 4);
     o->skws_bytes = (size_t)16 * W * W * 4;
     o->skws = (float*)a.take(o->skws_bytes);
     o->skws_side = lp ? (float*)a.take(o->skws_bytes) : o->skws;
@@ -266,6 +268,8 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
     for (int l = top; l >= 0; --l) {
         const sq_vis_layer_offsets& L = lay.layer[l];
         LayerG lg = b.lg[l];
+        sq_colsum_jobs csj;              // this layer's small column sums (3 LayerNorms + the combiner bias): one launch
+        sq_colsum_jobs* defer = sq_env_flag("SQ_BWD_NO_DEFER") ? nullptr : &csj;
         if (!lp) { lg.dXin_lp = dXcur; lg.dX1_lp = dXoth; }
         // ---------------- FeedForward: X2 = GELU(LN(X1) W1^T + b1) W2^T + b2 + X1 ----------------
         RUN(ready());
@@ -280,7 +284,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         { GemmArgs g = gemm(lg.dU, D, b.wt[l].ff1, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
         // dX1 = dX2 + dLN(dY)
         RUN(sq_k_ln_rows_bwd(b.dY, w.X1[l], Pf(L.ffln_g), dXcur, dXoth, lp ? (bf16_t*)lg.dX1_lp : nullptr, Gp_(L.ffln_g),
-                             Gp_(L.ffln_b), b.red_ws, M, D, st));
+                             Gp_(L.ffln_b), b.part_ws[0], M, D, st, defer));
         float* dX1 = dXoth;
 
         // ---------------- projection: X1 = O Wp^T + bp + X ----------------
@@ -301,7 +305,8 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         // ---------------- summary branch: per-slide tensors, small launches -> third stream, beside the local branch
         RUN(handoff(st, s2));
         RUN(sq_k_group_sum(lg.dP, dtype, B, N, HD, 1.0f, b.dCs, s2));       // dCs[b] = sum_n dP[b, n]
-        RUN(sq_k_colsum(b.dCs, SQ_F32, B, HD, HD, red2, Gp_(L.c_b), s2));
+        if (B <= 512 && defer) RUN(sq_colsum_jobs_add(&csj, b.dCs, B, HD, HD, Gp_(L.c_b), nullptr, 0));
+        else RUN(sq_k_colsum(b.dCs, SQ_F32, B, HD, HD, red2, Gp_(L.c_b), s2));
         if (lp) RUN(sq_k_cast_pad(b.dCs, HD, lg.dCs_lp, dtype, HD, B, HD, s2));
         RUN(handoff(s2, sst));
         {   // dWc_h[:, 64:] = dCs_h^T . Ts_h
@@ -316,7 +321,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
             g.splitk_ws = b.skws2; g.splitk_ws_bytes = b.skws2_bytes;
             RUN(sq_launch_gemm(g, dtype, s2));
         }
-        RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), lg.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), red2, B, HD, s2));
+        RUN(sq_k_ln64_gelu_bwd(b.dTs, w.Sm[l], Pf(L.lns_g), Pf(L.lns_b), lg.dSm, dtype, Gp_(L.lns_g), Gp_(L.lns_b), b.part_ws[1], B, HD, s2, defer));
         RUN(handoff(s2, sst));
         { GemmArgs g = gemm_tn(lg.dSm, HD, w.Xbar[l], D, Gp_(L.s_w), D, HD, D, B); g.colsum_a = Gp_(L.s_b); RUN(run_tn(g)); }
         {   // dXbar / N   (Xbar = mean_n X: every token of the slide receives dXbar / N)
@@ -334,11 +339,14 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), lg.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.red_ws, M, HD, st));
+        RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), lg.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.part_ws[2], M, HD, st, defer));
         RUN(ready());       // (the side stream has by now also waited for every summary-branch gradient of this layer)
         { GemmArgs g = gemm_tn(lg.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(run_tn(g)); }
         if (ev_xbar) SQ_HIP_CHECK(hipStreamWaitEvent(st, ev_xbar, 0));
-        if (l > 0) RUN(bucket_done_side(c->depth - l));
+        RUN(sq_k_colsum_multi(csj, st));              // needs the summary-branch partials: after the wait above
+        RUN(ready());                                 // the side stream sees the layer's last gradients ...
+        if (l > 0) RUN(bucket_done_side(c->depth - l));     // ... before it declares the bucket final
+
         {   // dXin = dF . Wf + dX1 (residual) + dXbar/N (per-slide row bias)
             GemmArgs g = gemm(lg.dF, HD, b.wt[l].f, HD, dXcur, D, M, D, HD);
             g.res = dX1; g.ldres = D; g.rowbias = b.dXbar; g.ldrb = D; g.rows_per_group = N;
