@@ -42,6 +42,10 @@ struct VisBufs {
 
 void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base, VisBufs* out);
 
+// summary branch of one layer, forward, in one launch (summary.hip; bf16 only)
+int sq_launch_summary_fwd(const void* Xbar, const void* Ws, const float* bs, const float* lng, const float* lnb, const void* Wc,
+                          const float* bc, float* Sm, void* Ts, float* Cs, int B, int D, int H, hipStream_t stream);
+
 // dtype of the saved GELU pre-activations (U, P): the operand dtype; SQ_F32_PREACT=1 keeps fp32 (A/B knob)
 inline int sq_vis_preact_dtype(int dtype) {
     static const int force32 = sq_env_flag("SQ_F32_PREACT") ? 1 : 0;

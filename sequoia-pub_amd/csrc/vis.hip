@@ -164,19 +164,25 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
             SQ_HIP_CHECK(hipStreamWaitEvent(s2, ev, 0));
         }
         if (int e = sq_k_token_mean(Xin, w.Xbar32[s], lp ? (bf16_t*)w.Xbar[s] : nullptr, B, N, D, s2)) return e;
-        {   // Sm = Xbar Ws^T + bs
-            GemmArgs g; g.A = w.Xbar[s]; g.lda = D; g.a_bytes = (size_t)B * D * es;
-            g.B = W(L.s_w); g.ldb = D; g.b_bytes = Wrem(L.s_w); g.bias = Pf(L.s_b);
-            g.C = w.Sm[s]; g.ldc = HD; g.M = B; g.N = HD; g.K = D; g.splitk_ws = w.skws; g.splitk_ws_bytes = w.skws_bytes;
-            if (int e = sq_launch_gemm(g, dtype, s2)) return e;
-        }
-        if (int e = sq_k_ln64_gelu(w.Sm[s], Pf(L.lns_g), Pf(L.lns_b), w.Ts[s], dtype, B, HD, s2)) return e;
-        {   // Cs[b, h] = Ts[b, h] . Wc_h[:, 64:128]^T + bc_h     (cat order: [local, summary], tformer_lin.py:24)
-            GemmArgs g; g.A = w.Ts[s]; g.lda = HD; g.a_bytes = (size_t)B * HD * es; g.sA = SQ_HEAD_DIM;
-            g.B = W(L.c_w + SQ_HEAD_DIM); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w + SQ_HEAD_DIM); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
-            g.bias = Pf(L.c_b); g.sBias = SQ_HEAD_DIM;
-            g.C = w.Cs[s]; g.ldc = HD; g.sC = SQ_HEAD_DIM; g.M = B; g.N = SQ_HEAD_DIM; g.K = SQ_HEAD_DIM; g.batch = H;
-            if (int e = sq_launch_gemm(g, dtype, s2)) return e;
+        if (lp && !sq_env_flag("SQ_FWD_NO_FUSED_SUMMARY")) {
+            // Sm = Xbar Ws^T + bs;  Ts = GELU(LN64(Sm));  Cs = Ts_h Wc_h[:, 64:]^T + bc_h  -- one launch (summary.hip)
+            if (int e = sq_launch_summary_fwd(w.Xbar[s], W(L.s_w), Pf(L.s_b), Pf(L.lns_g), Pf(L.lns_b), W(L.c_w), Pf(L.c_b), w.Sm[s],
+                                              w.Ts[s], w.Cs[s], B, D, H, s2)) return e;
+        } else {
+            {   // Sm = Xbar Ws^T + bs
+                GemmArgs g; g.A = w.Xbar[s]; g.lda = D; g.a_bytes = (size_t)B * D * es;
+                g.B = W(L.s_w); g.ldb = D; g.b_bytes = Wrem(L.s_w); g.bias = Pf(L.s_b);
+                g.C = w.Sm[s]; g.ldc = HD; g.M = B; g.N = HD; g.K = D; g.splitk_ws = w.skws; g.splitk_ws_bytes = w.skws_bytes;
+                if (int e = sq_launch_gemm(g, dtype, s2)) return e;
+            }
+            if (int e = sq_k_ln64_gelu(w.Sm[s], Pf(L.lns_g), Pf(L.lns_b), w.Ts[s], dtype, B, HD, s2)) return e;
+            {   // Cs[b, h] = Ts[b, h] . Wc_h[:, 64:128]^T + bc_h     (cat order: [local, summary], tformer_lin.py:24)
+                GemmArgs g; g.A = w.Ts[s]; g.lda = HD; g.a_bytes = (size_t)B * HD * es; g.sA = SQ_HEAD_DIM;
+                g.B = W(L.c_w + SQ_HEAD_DIM); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w + SQ_HEAD_DIM); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
+                g.bias = Pf(L.c_b); g.sBias = SQ_HEAD_DIM;
+                g.C = w.Cs[s]; g.ldc = HD; g.sC = SQ_HEAD_DIM; g.M = B; g.N = SQ_HEAD_DIM; g.K = SQ_HEAD_DIM; g.batch = H;
+                if (int e = sq_launch_gemm(g, dtype, s2)) return e;
+            }
         }
         if (fs) { ev_cs = fs->events[ev_next++]; SQ_HIP_CHECK(hipEventRecord(ev_cs, s2)); }
         {   // Lf = GELU(LN64(F)),  F = X Wf^T + bf: LayerNorm + GELU in the epilogue (a head's 64 columns sit in 8
