@@ -98,7 +98,8 @@ class ResNet50(nn.Module):
     # ---- packing -------------------------------------------------------------------------------
     def _pack(self):
         dev = self.conv1.weight.device
-        key = (dev, self.compute_dtype, tuple(p._version for p in self.parameters()))
+        # BatchNorm running statistics are folded into the packed weights too: buffer updates must repack
+        key = (dev, self.compute_dtype, tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()))
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1], self._packed[2]
         w, b = pack_weights(self.state_dict())
@@ -158,6 +159,7 @@ class ResNet50(nn.Module):
         # that depends on the previous one, so a single chain leaves the chip idle in each launch's ramp-up, tail and
         # store-drain phase; a second, independent chain fills those.
         main = torch.cuda.current_stream(dev)
+        self._pack()            # (re)pack on the main stream, ahead of `start`: the chains only wait on that event
         ns = max(1, int(os.environ.get("SQ_RESNET_STREAMS", "2")))
         if getattr(self, "_streams", None) is None or self._streams[0].device != dev or len(self._streams) != ns:
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]

@@ -81,9 +81,9 @@ def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=
     streams = model.__dict__.setdefault("_spatial_streams", None)
     if streams is None or streams[0].device != dev:
         streams = model.__dict__["_spatial_streams"] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-    start = torch.cuda.Event()
+    model._params_lp()                              # refresh the bf16 shadow on the main stream BEFORE the hand-over event:
+    start = torch.cuda.Event()                      # the window streams wait on `start` only and must see the finished cast
     start.record(main)
-    model._params_lp()                                                         # refresh the bf16 shadow once, on the main stream
     for i, s in enumerate(range(0, W, batch_windows)):
         st = streams[i % 2]
         st.wait_event(start)

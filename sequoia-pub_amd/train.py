@@ -10,7 +10,7 @@ What changes versus the reference is where the work runs, not what is computed:
     instead of three D2H copies + 20 820 ``np.corrcoef`` calls per batch (1.2 s/batch on CPU).
   * with ``torch.distributed`` initialised, the flat gradient is all-reduced over RCCL once per
     step and epoch scalars / stop decisions are reduced so every rank takes the same branch.
-Checkpoint naming, save/stop rules and return values follow the reference line by line.
+Checkpoint naming, save/stop rules (``CheckpointPolicy``) and return values are the reference's.
 """
 import ctypes
 import math
@@ -80,8 +80,21 @@ def _scratch(model):
     return s
 
 
+def _pair_f32(pred, target):
+    """The C entry points read packed f32 [B, G] arrays through raw pointers: bring both operands to that form on
+    pred's device (the reference's loss would up-cast / raise; garbage or out-of-bounds reads are not an option)."""
+    if not pred.is_cuda:
+        raise _lib.SequoiaHipError("loss / metrics run on the GPU: pred is on the CPU (no CPU fallback)")
+    pred = pred.detach().to(torch.float32).contiguous()
+    target = torch.as_tensor(target).detach().to(pred.device, torch.float32).contiguous()
+    if target.shape != pred.shape:
+        raise ValueError(f"target shape {tuple(target.shape)} != prediction shape {tuple(pred.shape)}")
+    return pred, target
+
+
 def mse_loss_grad(model, pred, target, grad_scale=None, want_grad=True):
     """nn.MSELoss() value (device scalar tensor) and d loss / d pred."""
+    pred, target = _pair_f32(pred, target)
     n = pred.numel()
     grad = torch.empty_like(pred) if want_grad else None
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
@@ -93,6 +106,9 @@ def mse_loss_grad(model, pred, target, grad_scale=None, want_grad=True):
 
 def batch_metrics(model, pred, target):
     """(MAE, mean per-gene Pearson, n_genes) of one batch as a device tensor [3] (vit.py:167-168)."""
+    pred, target = _pair_f32(pred, target)
+    if pred.dim() != 2:
+        raise ValueError(f"batch_metrics wants [B, G] predictions, got {tuple(pred.shape)}")
     out = torch.empty(3, dtype=torch.float32, device=pred.device)
     B, G = pred.shape
     _lib.check(_lib.lib().sq_batch_metrics(_lib.ptr(pred), _lib.ptr(target), B, G, _lib.ptr(out),
@@ -130,19 +146,36 @@ class FusedTrainStep:
                 for e in self.events:
                     e.record()              # instantiates the hipEvent_t the C side records into
 
-    def step(self, x, target):
+    def step(self, x, target, n_global=None):
+        """One optimizer step.  x [B, 100, D], target [B, G].  n_global: number of target elements of this step over
+        ALL ranks (default: every rank holds a batch like this one); a rank whose batch is empty passes x=None and
+        still joins the gradient exchange with zeros, so the collectives of the ranks stay matched.
+        Returns (loss, pred, metrics) of the local batch, or None for an empty local batch."""
         m = self.model
         dev = m.flat.device
-        B = x.shape[0]
-        pred = m._run_forward(x, save=True)
-        n_global = pred.numel() * self.world
-        loss, gpred = mse_loss_grad(m, pred, target, grad_scale=2.0 / n_global)
-        mets = batch_metrics(m, pred, target) if self.metrics else None
+        empty = x is None
+        if empty and not self.overlap:
+            raise ValueError("FusedTrainStep.step: empty batch on a single rank (the loop skips those, vit.py:159)")
+        if not empty:
+            B = x.shape[0]
+            pred = m._run_forward(x, save=True)
+            if n_global is None:
+                n_global = pred.numel() * self.world
+            loss, gpred = mse_loss_grad(m, pred, target, grad_scale=2.0 / n_global)
+            mets = batch_metrics(m, pred, target) if self.metrics else None
         if not self.overlap:
             gflat, _ = vis_backward(m, gpred, B, False)
         else:
             main = torch.cuda.current_stream(dev)
-            gflat, _ = vis_backward(m, gpred, B, False, bucket_events=self.events)
+            if empty:
+                gflat = getattr(m, "_gflat", None)
+                if gflat is None or gflat.shape != m.flat.shape or gflat.device != dev:
+                    gflat = m._gflat = torch.zeros_like(m.flat.detach())
+                gflat.zero_()
+                for e in self.events:
+                    e.record(main)
+            else:
+                gflat, _ = vis_backward(m, gpred, B, False, bucket_events=self.events)
             reduce_ = dist.is_available() and dist.is_initialized()
             for (lo, hi), ev in zip(self.buckets, self.events):
                 self.comm_stream.wait_event(ev)
@@ -158,7 +191,7 @@ class FusedTrainStep:
                                                 self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, 1.0,
                                                 _lib.stream_ptr(dev)))
         # the kernel refreshed the bf16 shadow in the same pass (flat._version is unchanged by C-side writes)
-        return loss, pred, mets
+        return None if empty else (loss, pred, mets)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -168,12 +201,91 @@ def _is_empty(image):
     return isinstance(image, list) and len(image) == 0
 
 
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def _all_mean(vals, device):
     """Mean over all batches of all ranks (each rank contributes its own list)."""
     t = torch.tensor([float(np.sum(vals)), float(len(vals))], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _dist_on():
         dist.all_reduce(t)
     return float(t[0] / t[1]) if float(t[1]) > 0 else float("nan")
+
+
+class CheckpointPolicy:
+    """When to write ``model_best*.pt`` and when to end training -- the decision rules of vit.py:199-242 as a small
+    state machine fed one (loss, score) pair per epoch.  Pinned by tests/golden/early_stop.json (events recorded
+    from the reference loop on scripted validation curves).
+
+    Two regimes.  Before the loss has gone `patience` epochs without a new minimum ("plateau"), a new minimum is
+    a checkpoint.  After the plateau, ``save_on='loss+corr'`` keeps checkpointing on new best SCORES instead, and
+    ``stop_on='loss+corr'`` keeps training until the score has been stale for `patience` epochs or the loss has
+    stayed `delta` above its minimum for `patience` epochs."""
+
+    def __init__(self, save_on="loss", stop_on="loss", patience=20, delta=0.5):
+        self.save_on, self.stop_on, self.patience, self.delta = save_on, stop_on, patience, delta
+        self.min_loss, self.max_score = np.inf, 0
+        self.age = {"loss": 0, "score": 0, "drift": 0}     # epochs since: loss minimum, score maximum, loss within delta
+        self.plateau = False
+
+    def observe(self, loss, score):
+        """One validation result.  Returns the list of reasons to checkpoint now ('loss' and / or 'score')."""
+        reasons = []
+        if self.plateau:
+            self.age["drift"] = 0 if loss < self.min_loss + self.delta else self.age["drift"] + 1
+        if loss < self.min_loss:
+            self.min_loss, self.age["loss"] = loss, 0
+            if self.save_on == "loss" or (self.save_on == "loss+corr" and not self.plateau):
+                reasons.append("loss")
+        else:
+            self.age["loss"] += 1
+        if score > self.max_score:
+            self.max_score, self.age["score"] = score, 0
+            if self.save_on == "loss+corr" and self.plateau:
+                reasons.append("score")
+        else:
+            self.age["score"] += 1
+        return reasons
+
+    def end_of_epoch(self, epoch):
+        """Returns the message of the stop rule that fired, or None to go on."""
+        if self.age["loss"] == self.patience:
+            self.plateau = True
+            if self.stop_on == "loss":
+                return f"Early stopping at epoch {epoch}!"
+        if self.stop_on == "loss+corr" and self.plateau:
+            if self.age["score"] == self.patience:
+                return f"Early stopping at epoch {epoch} because neither loss nor score is improving anymore!"
+            if self.age["drift"] == self.patience:
+                return f"Early stopping at epoch {epoch} because loss is not within {self.delta} of best loss anymore!"
+        return None
+
+
+def _global_count(n_local, device):
+    """Elements of this step's batch over all ranks (ranks may hold ragged or empty batches: collate drops
+    unreadable slides).  One tiny all-reduce; every rank must call it once per step."""
+    if not _dist_on():
+        return n_local
+    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def _paired_batches(loader, device):
+    """Iterate a rank's loader while all ranks agree on the number of steps: a rank whose loader is exhausted (or
+    that has no loader items left) keeps yielding None until every rank is done, so collectives stay matched."""
+    it = iter(loader)
+    while True:
+        item = next(it, None)
+        if _dist_on():
+            alive = torch.tensor([0.0 if item is None else 1.0], device=device)
+            dist.all_reduce(alive, op=dist.ReduceOp.MAX)
+            if float(alive.item()) == 0.0:
+                return
+        elif item is None:
+            return
+        yield item
 
 
 def train(model, dataloaders, optimizer=None, accelerator=None,
@@ -181,101 +293,97 @@ def train(model, dataloaders, optimizer=None, accelerator=None,
           run=None, verbose=True, phases=['train', 'val'], split=None,
           save_on='loss', stop_on='loss', delta=0.5, lr=1e-3):
     """Same contract as vit.py:117-243.  ``optimizer`` may be a torch optimizer over
-    ``model.parameters()`` (used through autograd) or None (fused AdamW step, the fast path)."""
+    ``model.parameters()`` (used through autograd) or None (fused AdamW step, the fast path).
+
+    Under torch.distributed every rank feeds its own shard of the training batches; the gradient of the step is
+    the gradient of the MSE over the union of the ranks' batches (summed over ranks, normalised by the global
+    element count), in both the fused and the torch-optimizer path.  A rank whose batch collated to nothing still
+    takes part in the exchange with a zero gradient."""
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if save_dir is not None and not os.path.exists(save_dir) and rank == 0:
         os.mkdir(save_dir)
-    if split:                                   # NB falsy for split 0 -> no suffix (vit.py:124)
-        save_path = os.path.join(save_dir, f'model_best_{split}.pt')
-    else:
-        save_path = os.path.join(save_dir, 'model_best.pt')
+    # vit.py:124: `if split:` -- fold 0 (and None) get no suffix
+    save_path = os.path.join(save_dir, f'model_best_{split}.pt' if split else 'model_best.pt')
 
     fused = FusedTrainStep(model, lr=lr, world_size=world, metrics=True) if optimizer is None else None
     dev = model.flat.device
-    epoch_since_best = 0
-    best_loss = np.inf
-    early_stop_on_loss_triggered = 0
-    epoch_since_best_score = 0
-    best_score = 0
-    epoch_since_ok_loss = 0
-
-    def save():
-        if rank == 0:
-            torch.save(model.state_dict(), save_path)
+    policy = CheckpointPolicy(save_on, stop_on, patience, delta)
+    observing = [ph for ph in phases if ph == 'val'] or (list(phases) if len(phases) == 1 else [])
 
     for epoch in range(num_epochs):
         for phase in phases:
-            model.train() if phase == 'train' else model.eval()
-            losses, maes, scores = [], [], []
-            for s, (image, rna_data, _, _) in enumerate(dataloaders[phase]):
-                if _is_empty(image):
-                    continue
-                image = image.to(dev)
-                rna_data = rna_data.to(dev)
-                if phase == 'train' and fused is not None:
-                    loss, pred, mets = fused.step(image, rna_data)
+            training = phase == 'train'
+            model.train() if training else model.eval()
+            loader = dataloaders[phase]
+            reshuffle = getattr(getattr(loader, "sampler", None), "set_epoch", None)
+            if reshuffle is not None:
+                reshuffle(epoch)                                  # DistributedSampler: a new permutation every epoch
+            stats = []                                            # per batch: (loss, mae, score)
+            for batch in (_paired_batches(loader, dev) if (training and world > 1) else loader):
+                image, rna_data = (batch[0], batch[1]) if batch is not None else ([], None)
+                empty = _is_empty(image)
+                if empty and not (training and world > 1):
+                    continue                                      # vit.py:159
+                if not empty:
+                    image, rna_data = image.to(dev), rna_data.to(dev)
+                if training:
+                    n_local = 0 if empty else rna_data.numel()
+                    n_global = _global_count(n_local, dev) if world > 1 else n_local
+                    if fused is not None:
+                        res = fused.step(None if empty else image, rna_data, n_global=n_global)
+                        res = None if res is None else (res[0], res[2])
+                    else:
+                        res = _autograd_step(model, optimizer, None if empty else image, rna_data, n_global, world)
+                    if res is None:
+                        continue
+                    loss, mets = res
                 else:
-                    with torch.set_grad_enabled(phase == 'train'):
+                    with torch.no_grad():
                         pred = model(image)
-                    loss, gpred = mse_loss_grad(model, pred.detach(), rna_data, want_grad=phase == 'train')
-                    mets = batch_metrics(model, pred.detach(), rna_data)
-                    if phase == 'train':
-                        optimizer.zero_grad()
-                        pred.backward(gpred)
-                        optimizer.step()
-                vals = torch.cat([loss, mets[:2]]).cpu().numpy()          # one small D2H per batch
-                losses.append(vals[0]); maes.append(vals[1]); scores.append(vals[2])
-            L, A, S = _all_mean(losses, dev), _all_mean(maes, dev), _all_mean(scores, dev)
-            suffix = 'id' if phase == 'val' else ''
+                    loss, _ = mse_loss_grad(model, pred, rna_data, want_grad=False)
+                    mets = batch_metrics(model, pred, rna_data)
+                stats.append(torch.cat([loss, mets[:2]]).cpu().numpy())           # one small D2H per batch
+            cols = list(zip(*stats)) if stats else ([], [], [])
+            L, A, S = (_all_mean(c, dev) for c in cols)
+            tag = 'id' if phase == 'val' else ''
             if run and rank == 0:
-                run.log({'epoch': epoch, f'score {phase}{suffix} {split}': S})
-                run.log({'epoch': epoch, f'{phase}{suffix} loss fold {split}': L})
-                run.log({'epoch': epoch, f'{phase}{suffix} mae fold {split}': A})
+                run.log({'epoch': epoch, f'score {phase}{tag} {split}': S})
+                run.log({'epoch': epoch, f'{phase}{tag} loss fold {split}': L})
+                run.log({'epoch': epoch, f'{phase}{tag} mae fold {split}': A})
             if verbose and rank == 0:
                 print(f'Epoch {epoch}: {phase} loss {L} mae {A}')
-
-            if (phase == 'val') or (len(phases) == 1):
-                if early_stop_on_loss_triggered == 1:
-                    if L < (best_loss + delta):
-                        epoch_since_ok_loss = 0
-                    else:
-                        epoch_since_ok_loss += 1
-                if L < best_loss:
-                    best_loss = L
-                    epoch_since_best = 0
-                    if save_on == 'loss':
-                        save()
-                    elif (save_on == 'loss+corr') and (early_stop_on_loss_triggered == 0):
-                        save()
-                else:
-                    epoch_since_best += 1
-                if S > best_score:
-                    best_score = S
-                    epoch_since_best_score = 0
-                    if (save_on == 'loss+corr') and (early_stop_on_loss_triggered == 1):
-                        save()
-                        if rank == 0:
+            if phase in observing:
+                for why in policy.observe(L, S):
+                    if rank == 0:
+                        torch.save(model.state_dict(), save_path)
+                        if why == "score":
                             print(f'Saved model on loss+corr at epoch {epoch} of better score and loss within {delta} of optimal loss')
-                else:
-                    epoch_since_best_score += 1
-
-        if epoch_since_best == patience:
-            early_stop_on_loss_triggered = 1
-            if stop_on == 'loss':
-                if rank == 0:
-                    print(f'Early stopping at epoch {epoch}!')
-                break
-        if stop_on == 'loss+corr':
-            if (early_stop_on_loss_triggered == 1) and (epoch_since_best_score == patience):
-                if rank == 0:
-                    print(f'Early stopping at epoch {epoch} because neither loss nor score is improving anymore!')
-                break
-            if (early_stop_on_loss_triggered == 1) and (epoch_since_ok_loss == patience):
-                if rank == 0:
-                    print(f'Early stopping at epoch {epoch} because loss is not within {delta} of best loss anymore!')
-                break
+        verdict = policy.end_of_epoch(epoch)
+        if verdict is not None:
+            if rank == 0:
+                print(verdict)
+            break
     return model          # last-epoch model, not the best checkpoint (vit.py:243)
+
+
+def _autograd_step(model, optimizer, image, rna_data, n_global, world):
+    """``loss.backward(); optimizer.step()`` of vit.py:175-180 with a torch optimizer over model.parameters().
+    Returns (loss, metrics) of the local batch, or None when this rank had nothing to show."""
+    optimizer.zero_grad()
+    out = None
+    if image is not None:
+        pred = model(image)
+        loss, gpred = mse_loss_grad(model, pred.detach(), rna_data, grad_scale=2.0 / max(n_global, 1))
+        mets = batch_metrics(model, pred.detach(), rna_data)
+        pred.backward(gpred)
+        out = (loss, mets)                                     # the loss VALUE is the local batch's mean, as on one rank
+    if world > 1:
+        if model.flat.grad is None:
+            model.flat.grad = torch.zeros_like(model.flat)
+        dist.all_reduce(model.flat.grad)
+    optimizer.step()
+    return out
 
 
 def evaluate(model, dataloader, run=None, verbose=True, suff=''):
@@ -326,28 +434,3 @@ def predict(model, dataloader, run=None, verbose=True):
         with torch.no_grad():
             preds.append(model(image.to(dev)).cpu().numpy())
     return np.concatenate(preds, axis=0), np.concatenate(wsis, axis=0), np.concatenate(projs, axis=0)
-
-
-def smoke_check():
-    """Tiny fwd+bwd+AdamW step on cuda:0 against the oracle (called from __graft_entry__.smoke)."""
-    from oracle import vis_oracle
-    from .vis import ViS
-    cfg = dict(num_outputs=200, input_dim=256, depth=2, nheads=4, dimensions_f=64, dimensions_s=64, dimensions_c=64)
-    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=1), seed=2)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(3, 100, 256, generator=g)
-    y = torch.rand(3, 200, generator=g) * 8
-    loss_ref, _, grads_ref = vis_oracle.vis_loss_and_grads(sd, x, y)
-    m = ViS(**cfg, device="cuda:0")
-    m.load_state_dict(sd)
-    m.to("cuda:0")
-    pred = m(x.cuda())
-    loss, gpred = mse_loss_grad(m, pred.detach(), y.cuda())
-    pred.backward(gpred)
-    gv = m.grad_views(m.flat.grad)
-    worst = 0.0
-    for k, gr in grads_ref.items():
-        e = float((gv[k].cpu() - gr).abs().max() / max(float(gr.abs().max()), 1e-12))
-        worst = max(worst, e)
-    print(f"smoke: ViS backward fp32 worst per-tensor rel err vs oracle {worst:.3e}; loss {float(loss):.6f} vs {float(loss_ref):.6f}")
-    assert worst < 1e-3 and abs(float(loss) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))

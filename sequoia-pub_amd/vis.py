@@ -86,6 +86,7 @@ class _VisFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flat, x, module, need_grad):
         out = module._run_forward(x, save=need_grad)
+        ctx.saved_gen = module._saved_gen if need_grad else None     # which saving forward this node belongs to
         ctx.module = module
         ctx.need_x_grad = x.requires_grad
         ctx.batch = x.shape[0]
@@ -95,6 +96,12 @@ class _VisFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         module = ctx.module
+        if ctx.saved_gen is None or ctx.saved_gen != module._saved_gen:
+            # the activations live in ONE per-module workspace: a later forward (another micro-batch, an eval pass with
+            # a different batch size, ...) has overwritten what this node saved -- refuse instead of returning garbage
+            raise RuntimeError("ViS.backward: the saved activations of this forward were overwritten by a later forward "
+                               "of the same module; call backward() before the next grad-enabled forward "
+                               "(one forward in flight per module)")
         gflat, gx = module._run_backward(grad_out.contiguous(), ctx.batch, ctx.need_x_grad)
         if gx is not None:
             gx = gx.reshape(ctx.x_shape)
@@ -286,6 +293,8 @@ class ViS(nn.Module, PyTorchModelHubMixin):
                                                          _lib.ptr(lp), _lib.ptr(x), _lib.ptr(out), B, int(save),
                                                          _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)))
         self._saved_x = x if save else None
+        if slot == 0:           # slot-0 workspace rewritten (or re-allocated): earlier saved activations are gone
+            self._saved_gen = self.__dict__.get("_saved_gen", 0) + 1
         return out
 
     def _run_backward(self, grad_out, batch, need_x_grad):

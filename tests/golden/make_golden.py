@@ -298,8 +298,103 @@ def gold_evalstats():
     print("evalstats: mean r", np.nanmean(out["pred_real_r"]), "steiger p[0:3]", out["Steiger_p"][:3])
 
 
+def gold_early_stop():
+    """Save / early-stop decisions of the reference train() (vit.py:199-242) as a table: for several
+    (save_on, stop_on, patience, delta) settings and scripted validation curves, which epochs wrote the checkpoint
+    and at which epoch the loop ended.  The 'model' is a scripted stub whose e-th forward returns a prescribed
+    prediction, so the reference loop itself computes the loss / score sequence (phases=['val']: no optimizer use)."""
+    import contextlib, io, json, tempfile
+
+    class Scripted(torch.nn.Module):
+        device = "cpu"
+
+        def __init__(self, preds):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))      # state_dict() must not be empty for torch.save
+            self.preds, self.calls = preds, 0
+
+        def forward(self, x):
+            p = self.preds[self.calls]
+            self.calls += 1
+            return p
+
+    rs = np.random.RandomState(23)
+    B, G = 8, 6
+    target = torch.from_numpy((rs.rand(B, G) * 6).astype(np.float32))
+    tc = target - target.mean(0, keepdim=True)
+    noise = torch.from_numpy(rs.randn(B, G).astype(np.float32))
+
+    def curve(kind, n):
+        # (gain on the centred target, noise level) per epoch: shapes the loss and the per-gene Pearson score
+        e = np.arange(n)
+        if kind == "improve_then_flat":
+            c = np.where(e < 6, 2.0 - 0.3 * e, 0.5 + 0.01 * (e % 3))
+            s = np.ones(n)
+        elif kind == "improve_then_worse":
+            c = np.where(e < 5, 2.0 - 0.35 * e, 0.6 + 0.12 * (e - 5))
+            s = np.ones(n)
+        elif kind == "score_keeps_rising":
+            c = np.where(e < 4, 1.5 - 0.3 * e, 0.61 + 0.002 * e)
+            s = np.where(e < 4, 1.0, 1.0 + 0.02 * (e - 4))
+        elif kind == "noisy":
+            c = 1.0 + 0.5 * np.sin(e * 1.3) + 0.02 * e
+            s = 1.0 + 0.3 * np.cos(e * 0.7)
+        else:
+            raise ValueError(kind)
+        return s, c
+
+    cases = []
+    for kind in ("improve_then_flat", "improve_then_worse", "score_keeps_rising", "noisy"):
+        for save_on, stop_on in (("loss", "loss"), ("loss+corr", "loss+corr"), ("loss+corr", "loss"), ("loss", "loss+corr")):
+            for patience, delta in ((3, 0.5), (5, 0.05)):
+                n = 40
+                s, c = curve(kind, n)
+                preds = [target.mean(0, keepdim=True) + float(s[e]) * tc + float(c[e]) * noise for e in range(n)]
+                model = Scripted(preds)
+                saves = []
+                real_save = torch.save
+                torch.save = lambda obj, path: saves.append(model.calls - 1)      # epoch index of the forward just done
+                buf = io.StringIO()
+                try:
+                    with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(buf), warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        ref_vit.train(model, {"val": [(torch.zeros(B, 1), target, ["w"] * B, ["P"] * B)]}, None,
+                                      num_epochs=n, save_dir=d, patience=patience, phases=["val"], split=None,
+                                      save_on=save_on, stop_on=stop_on, delta=delta)
+                finally:
+                    torch.save = real_save
+                lines = [l for l in buf.getvalue().splitlines() if l.startswith("Epoch")]
+                losses = [float(l.split("loss")[1].split("mae")[0]) for l in lines]
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    scores = [float(compute_correlations(target.numpy(), preds[e].numpy())) for e in range(model.calls)]
+                cases.append(dict(kind=kind, save_on=save_on, stop_on=stop_on, patience=patience, delta=delta,
+                                  losses=losses, scores=scores, save_epochs=saves, epochs_run=model.calls,
+                                  stopped_early=model.calls < n))
+    with open(os.path.join(HERE, "early_stop.json"), "w") as f:
+        json.dump(cases, f)
+    print("early_stop:", len(cases), "cases; epochs run", sorted({c["epochs_run"] for c in cases}))
+
+
+def gold_kfold():
+    """Row-index lists of the reference's patient_kfold (src/utils.py:79-110) on seeded patient columns."""
+    import json
+    import pandas as pd
+    import src.utils as ref_utils                       # imports h5py: stubbed above
+    rs = np.random.RandomState(1)
+    cases = []
+    for n, npat, vs in ((40, 20, 0.1), (137, 51, 0.1), (512, 512, 0.1), (300, 17, 0.25), (64, 30, 0.0)):
+        pids = [f"P{p}" for p in rs.randint(0, npat, n)]
+        tr, va, te = ref_utils.patient_kfold(pd.DataFrame(dict(patient_id=pids)), n_splits=5, valid_size=vs)
+        cases.append(dict(patient_id=pids, valid_size=vs, train=[x.tolist() for x in tr], valid=[x.tolist() for x in va],
+                          test=[x.tolist() for x in te]))
+    with open(os.path.join(HERE, "kfold.json"), "w") as f:
+        json.dump(cases, f)
+    print("kfold:", len(cases), "cases")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats"]
+    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats", "early_stop", "kfold"]
     if "vit_tiny" in which:
         gold_vit_tiny()
     if "vis_tiny" in which:
@@ -314,3 +409,7 @@ if __name__ == "__main__":
         gold_metrics_and_train()
     if "evalstats" in which:
         gold_evalstats()
+    if "early_stop" in which:
+        gold_early_stop()
+    if "kfold" in which:
+        gold_kfold()

@@ -112,3 +112,35 @@ def _gloo_worker(rank, world, port, tmp):
 def test_world_size_2_gloo(tmp_path):
     port = 29500 + (os.getpid() % 1000)
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+def test_patient_kfold_equals_reference_golden(golden_dir):
+    """tests/golden/kfold.json: index lists produced by the reference's own patient_kfold (make_golden.py)."""
+    import json
+    for case in json.load(open(os.path.join(golden_dir, "kfold.json"))):
+        df = pd.DataFrame(dict(patient_id=case["patient_id"]))
+        tr, va, te = patient_kfold(df, n_splits=5, valid_size=case["valid_size"])
+        for got, want in ((tr, case["train"]), (va, case["valid"]), (te, case["test"])):
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                assert g.tolist() == w
+
+
+def test_checkpoint_policy_equals_reference_trace(golden_dir):
+    """tests/golden/early_stop.json: which epochs the reference train() saved at and where it stopped, for scripted
+    validation curves (make_golden.py gold_early_stop) -- the save / stop state machine must reproduce every row."""
+    import json
+    from sequoia_pub_amd.train import CheckpointPolicy
+    cases = json.load(open(os.path.join(golden_dir, "early_stop.json")))
+    assert len(cases) >= 32 and any(c["stopped_early"] for c in cases)
+    for c in cases:
+        pol = CheckpointPolicy(c["save_on"], c["stop_on"], c["patience"], c["delta"])
+        saves, ran = [], 0
+        for epoch, (loss, score) in enumerate(zip(c["losses"], c["scores"])):
+            ran += 1
+            if pol.observe(loss, score):
+                saves.append(epoch)
+            if pol.end_of_epoch(epoch) is not None:
+                break
+        assert saves == c["save_epochs"], (c["kind"], c["save_on"], c["stop_on"], c["patience"])
+        assert ran == c["epochs_run"], (c["kind"], c["save_on"], c["stop_on"], c["patience"])
