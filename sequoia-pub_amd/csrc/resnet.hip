@@ -15,6 +15,9 @@
 #include "../../include/sequoia_hip.h"
 #include "gemm.h"
 
+int sq_launch_bottleneck_tail_c64(const bf16_t* t1, const bf16_t* res, bf16_t* y, bf16_t* t1n, int cn,
+                                  const bf16_t* w2, const bf16_t* w3, const bf16_t* w1n, size_t w2_bytes, size_t w3_bytes, size_t w1n_bytes,
+                                  const float* b2, const float* b3, const float* b1n, int n_img, int H, int W, hipStream_t stream);
 int sq_launch_conv1_pool_bf16(const uint8_t* u8, const float* f32_nchw, const bf16_t* w152, const float* bias, bf16_t* out,
                               int n, int S, hipStream_t stream);
 
@@ -272,18 +275,41 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
             SQ_LAUNCH_CHECK();
         }
     }
-    // bottleneck stack: x lives in act[xi]; t1, t2, ds, y are the other four buffers
-    int xi = 1, ci = 1;
+    // bottleneck stack: x lives in act[xi]; t1, t2, ds, y are taken from the other four buffers.
+    // bf16, 56 x 56 stage (layer 1): the 3x3, the expand 1x1 (+ identity, ReLU) and the NEXT block's reduce 1x1 are one
+    // launch (bottleneck.hip) -- that block's conv1 output then already sits in act[t1i] when its turn comes.
+    const bool fuse56 = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && (128 + 2 * H + 2) * 128 <= 32768;
+    int xi = 1, ci = 1, t1i = -1;
     const int blocks[4] = {3, 4, 6, 3};
     for (int li = 0; li < 4; ++li)
         for (int bk = 0; bk < blocks[li]; ++bk) {
             int free_[4], nf = 0;
-            for (int i = 0; i < 5; ++i) if (i != xi) free_[nf++] = i;
-            void* x = b.act[xi]; void* t1 = b.act[free_[0]]; void* t2 = b.act[free_[1]]; void* ds = b.act[free_[2]]; void* y = b.act[free_[3]];
+            for (int i = 0; i < 5; ++i) if (i != xi && i != t1i) free_[nf++] = i;
+            void* x = b.act[xi];
+            void* t1 = t1i >= 0 ? b.act[t1i] : b.act[free_[--nf]];
             const sq_conv_desc& c1 = lay.conv[ci]; const sq_conv_desc& c2 = lay.conv[ci + 1]; const sq_conv_desc& c3 = lay.conv[ci + 2];
             const bool has_ds = bk == 0;
             const int OH = H / c2.stride;
-            RUN(conv(c1, x, H, t1, H, nullptr, SQ_ACT_RELU));
+            if (t1i < 0) RUN(conv(c1, x, H, t1, H, nullptr, SQ_ACT_RELU));
+            const int cnext = ci + (has_ds ? 4 : 3);
+            if (fuse56 && li == 0) {
+                void* ds = b.act[free_[0]]; void* y = b.act[free_[1]]; void* t1n = b.act[free_[2]];
+                const void* identity = x;
+                if (has_ds) {
+                    RUN(conv(lay.conv[ci + 3], x, H, ds, OH, nullptr, SQ_ACT_NONE));
+                    identity = ds;
+                }
+                const sq_conv_desc& n1 = lay.conv[cnext];
+                auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
+                RUN(sq_launch_bottleneck_tail_c64((const bf16_t*)t1, (const bf16_t*)identity, (bf16_t*)y, (bf16_t*)t1n, n1.cout,
+                                                  (const bf16_t*)W(c2), (const bf16_t*)W(c3), (const bf16_t*)W(n1), rest(c2), rest(c3), rest(n1),
+                                                  bias + c2.b_off, bias + c3.b_off, bias + n1.b_off, n, H, H, st));
+                xi = free_[1];
+                t1i = free_[2];
+                ci = cnext;
+                continue;
+            }
+            void* t2 = b.act[free_[0]]; void* ds = b.act[free_[1]]; void* y = b.act[free_[2]];
             RUN(conv(c2, t1, H, t2, OH, nullptr, SQ_ACT_RELU));
             const void* identity = x;
             if (has_ds) {
@@ -291,8 +317,9 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                 identity = ds;
             }
             RUN(conv(c3, t2, OH, y, OH, identity, SQ_ACT_RELU));       // relu(bn3(conv3) + identity)
-            ci += has_ds ? 4 : 3;
-            xi = free_[3];
+            ci = cnext;
+            xi = free_[2];
+            t1i = -1;
             H = OH;
         }
     {

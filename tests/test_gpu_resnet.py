@@ -67,3 +67,26 @@ def test_two_streams_in_flight_equal_one(monkeypatch):
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert torch.equal(a, c)                                      # sub-batching itself does not change a patch's features
+
+
+def test_fused_bottleneck_tail_is_bit_identical(monkeypatch):
+    """bf16, 56 x 56 stage: the fused launch (3x3 -> expand + identity -> next block's reduce, csrc/bottleneck.hip)
+    against the same network run as separate GEMM-engine launches (SQ_RESNET_NO_FUSE=1): identical bits, for a patch
+    count whose pixel total is not a multiple of the 128-pixel tile and for single patches (image borders inside a tile)."""
+    _lib.require_gpu()
+    torch.manual_seed(5)
+    rn = resnet50(pretrained=False, compute_dtype="bf16").to("cuda:0").eval()
+    for m in rn.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    for npatch in (1, 3, 7):
+        patches = torch.from_numpy(synth.patches_u8(11 + npatch, npatch, 224)).cuda()
+        monkeypatch.delenv("SQ_RESNET_NO_FUSE", raising=False)
+        fused = rn.extract_patches_u8(patches)
+        monkeypatch.setenv("SQ_RESNET_NO_FUSE", "1")
+        plain = rn.extract_patches_u8(patches)
+        torch.cuda.synchronize()
+        assert torch.isfinite(fused).all()
+        assert torch.equal(fused, plain), (npatch, float((fused - plain).abs().max()))
+    monkeypatch.delenv("SQ_RESNET_NO_FUSE", raising=False)
