@@ -1,11 +1,16 @@
 #!/usr/bin/env python
 """bench.py -- slides/sec of the SEQUOIA hot path on MI355X (driver contract in the task brief).
 
-    python bench.py --gpus N --steps K --warmup W [--workload vis_train|vis_fwd|pipeline] [--dtype bf16|fp32]
+    python bench.py --gpus N --steps K --warmup W [--workload pipeline|vis_train|vis_fwd|train_kfold|spatial] [--dtype bf16|fp32]
 
-One process per GPU (torchrun / torch.distributed.run launches N of them); slides are
-independent units, so ranks shard them with no data-path collective.  Only the training
-workload has an exchange step: the RCCL all-reduce of the flat gradient buffer.
+Default workload = the headline configuration of BASELINE.json's metric (config 3): 1000 x 224 x 224 uint8
+patches per slide -> ResNet-50 embed -> k-Means(100) -> ViS forward, bf16, patches resident in HBM when the timed
+region starts.  The same JSON line carries ``secondary``: the PCIe-inclusive twin (patches uploaded from pinned host
+memory every step), BASELINE config 2 (``vis_train``) and the fp32 parity-mode pipeline, each timed the same way.
+
+One process per GPU: with --gpus N > 1 and no WORLD_SIZE in the environment bench.py starts the N ranks itself
+(torch.distributed.run); slides are independent units, so ranks shard them with no data-path collective.  Only the
+training workloads have an exchange step: the RCCL all-reduce of the flat gradient buffer.
 
 Prints ONE JSON line on rank 0 with the headline value plus:
   roofline     -- dominant kernel, algorithmic FLOP (or bytes) per launch / HIP-event duration,
@@ -15,6 +20,7 @@ Prints ONE JSON line on rank 0 with the headline value plus:
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -119,12 +125,15 @@ def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
                  "timed": "helper streams off during the profiled steps (kernels one at a time)"})
     # HBM-side bytes per launch of this kernel/shape from the committed rocprofv3 PMC passes of the same command
     # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py)
-    pmc = os.path.join(ROOT, "profiles", f"r01_{workload_name}_{dtype_name}_pmc.json")
-    if os.path.exists(pmc):
-        cls = json.load(open(pmc)).get("classes", {}).get(dom["name"])
-        if cls and "hbm_bytes_avg" in cls:
-            roof["traffic"] = cls["hbm_bytes_avg"]
-            roof["traffic_source"] = os.path.relpath(pmc, ROOT)
+    roof["traffic_measured"] = False          # read from the committed PMC passes of the same command, not from this run
+    for rnd in ("r02", "r01"):
+        pmc = os.path.join(ROOT, "profiles", f"{rnd}_{workload_name}_{dtype_name}_pmc.json")
+        if os.path.exists(pmc):
+            cls = json.load(open(pmc)).get("classes", {}).get(dom["name"])
+            if cls and "hbm_bytes_avg" in cls:
+                roof["traffic"] = cls["hbm_bytes_avg"]
+                roof["traffic_source"] = os.path.relpath(pmc, ROOT)
+                break
     return roof, recs
 
 
@@ -271,14 +280,24 @@ def workload_pipeline(args, rank, world, device):
             run(slides)
 
     def cpu_baseline():
+        """BASELINE config 1 on this host's cores, bounded: the literal batch-1 patch loop of
+        compute_features_hdf5.py:116-123 (one forward + one result copy per patch) on a sample of patches, the same
+        sample batched (so the speed-up is not inflated by the reference's loop structure), then ONE oracle
+        k-Means(100) + cluster means + ViS forward; per-slide time = 1000 x per-patch time + the rest."""
         from oracle import kmeans_oracle, resnet_oracle, vis_oracle
         sd_r = {k: v.cpu() for k, v in rn.state_dict().items()}
         sd_v = {k: v.cpu() for k, v in vis.state_dict().items()}
-        patches = host[0][:32]
-
-        def embed():
-            resnet_oracle.embed_patches(sd_r, patches, batch=32)
-        rate, threads, reps = timed_cpu_sample(embed, 32, budget_s=10.0)
+        ncpu = os.cpu_count() or 1
+        torch.set_num_threads(min(ncpu, 64))
+        n_lit, n_bat = 96, 128
+        sample = host[0][:n_bat].cpu() if isinstance(host[0], torch.Tensor) else host[0][:n_bat]
+        resnet_oracle.embed_patches(sd_r, sample[:2], batch=1)                      # warm the thread pool
+        t0 = time.perf_counter()
+        out = [resnet_oracle.embed_patches(sd_r, sample[i:i + 1], batch=1)[0].numpy() for i in range(n_lit)]
+        t_lit = (time.perf_counter() - t0) / n_lit
+        t0 = time.perf_counter()
+        resnet_oracle.embed_patches(sd_r, sample, batch=n_bat)
+        t_bat = (time.perf_counter() - t0) / n_bat
         feats = synth.features_gmm(5, npatch, 2048)
         t0 = time.perf_counter()
         r = kmeans_oracle.kmeans_fit(feats)
@@ -286,10 +305,13 @@ def workload_pipeline(args, rank, world, device):
         with torch.no_grad():
             vis_oracle.vis_forward(sd_v, torch.from_numpy(cf)[None])
         t_rest = time.perf_counter() - t0
-        per_slide = npatch / rate + t_rest
-        return {"value": round(1.0 / per_slide, 5), "unit": "slides/s", "cores": threads, "kind": "port",
-                "sample": f"oracle ResNet-50 on {reps} x 32 patches (batched; {rate:.1f} patches/s) extrapolated to "
-                          f"{npatch} patches + one oracle k-Means + ViS forward ({t_rest:.2f} s)"}
+        lit, bat = 1.0 / (npatch * t_lit + t_rest), 1.0 / (npatch * t_bat + t_rest)
+        return {"value": round(lit, 5), "unit": "slides/s", "cores": torch.get_num_threads(), "kind": "port",
+                "batched_value": round(bat, 5),
+                "sample": f"config 1 restated (oracle/, torch-CPU fp32): literal batch-1 loop on {n_lit} patches "
+                          f"({t_lit * 1e3:.1f} ms/patch) and the same arithmetic in one batch of {n_bat} ({t_bat * 1e3:.1f} ms/patch), "
+                          f"each extrapolated to {npatch} patches, + one oracle k-Means(100) + cluster means + ViS(D=2048) forward "
+                          f"({t_rest:.2f} s); value = literal, batched_value = batched"}
 
     return dict(step=step, flush=None if args.no_stream else pipe.flush, slides_per_step=nslides, cpu_baseline=cpu_baseline,
                 config={"workload": "pipeline: 1000 x 224x224 uint8 patches/slide -> ResNet-50 embed -> k-Means(100) -> "
@@ -336,17 +358,143 @@ def workload_spatial(args, rank, world, device):
                         "parallelism": f"slide-sharded x{world}"})
 
 
-WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train, "pipeline": workload_pipeline, "spatial": workload_spatial}
+def workload_train_kfold(args, rank, world, device):
+    """BASELINE config 4: src/main.py:101-219 semantics on synthetic slides -- 64 slides per GPU (512 on 8 GPUs), one
+    slide per synthetic patient, patient_kfold 5 folds; per fold a freshly initialised ViS is trained for
+    --epochs epochs (train + val phases through train(): fused step, device-side metrics, RCCL gradient all-reduce
+    under DDP, save / stop policy without checkpoint files) and evaluated on the fold's test part.
+    A step = one full 5-fold pass; slides/s counts every slide forward (train, val and test)."""
+    import pandas as pd
+    from sequoia_pub_amd import train as sq_train
+    from sequoia_pub_amd.data import patient_kfold
+    per_gpu, E = args.batch, args.epochs
+    n = per_gpu * world
+    model = make_vis(args.dtype, device)
+    init = model.flat.detach().clone()
+    df = pd.DataFrame(dict(patient_id=[f"P{i:05d}" for i in range(n)]))
+    folds = list(zip(*patient_kfold(df, n_splits=5)))
+    # every rank materialises only its own rows (row r lives on rank r % world), already on the device
+    mine = np.arange(rank, n, world)
+    x_all = torch.from_numpy(synth.cluster_tokens(99 + rank, len(mine), 1024)).to(device)
+    y_all = torch.from_numpy(synth.rna_targets(199 + rank, len(mine), VIS_CFG["num_outputs"])).to(device)
+    pos = {int(r): i for i, r in enumerate(mine)}
+
+    def loader(rows):
+        sel = torch.as_tensor([pos[int(r)] for r in rows if int(r) in pos], dtype=torch.long, device=device)
+        if sel.numel() == 0:
+            return [([], [], [], [])]
+        names = [f"slide{int(r)}" for r in rows if int(r) in pos]
+        return [(x_all[sel[i:i + per_gpu]], y_all[sel[i:i + per_gpu]], names[i:i + per_gpu], ["SYN"] * len(names[i:i + per_gpu]))
+                for i in range(0, sel.numel(), per_gpu)]
+
+    def step():
+        for i, (tr, va, te) in enumerate(folds):
+            with torch.no_grad():
+                model.flat.copy_(init)                       # main.py:165: a new model per fold (bumps the version: bf16 shadow refreshed)
+            sq_train.train(model, {"train": loader(tr), "val": loader(va)}, None, num_epochs=E, save_dir=None,
+                           verbose=False, split=i, lr=1e-3)
+            sq_train.evaluate(model, loader(te), verbose=False)
+
+    def cpu_baseline():
+        from oracle import vis_oracle
+        sd = {k: v.cpu() for k, v in model.state_dict().items()}
+        nb = 8
+        xc, yc = x_all[:nb].cpu(), y_all[:nb].cpu()
+        m = {k: torch.zeros_like(v) for k, v in sd.items()}
+        v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+        state = {"step": 0}
+
+        def call():
+            _, _, grads = vis_oracle.vis_loss_and_grads(sd, xc, yc)
+            state["step"] += 1
+            vis_oracle.adamw_step(sd, grads, m, v2, state["step"])
+        rate, threads, reps = timed_cpu_sample(call, nb)
+        return {"value": round(rate, 3), "unit": "slides/s", "cores": threads, "kind": "port",
+                "sample": f"oracle ViS fwd+bwd+AdamW (torch-CPU fp32 autograd), {reps} steps x batch {nb}; host-side metrics not included"}
+
+    return dict(step=step, slides_per_step=per_gpu * (4 * E + 1), cpu_baseline=cpu_baseline,
+                config={"workload": f"train_kfold: {n} synthetic slides ({per_gpu}/GPU), patient_kfold 5 folds, {E} epochs per fold "
+                                    "(train + val) + test evaluation, ViS(D=1024, depth 6, 16 heads, G=20820) (BASELINE config 4)",
+                        "slides": n, "epochs_per_fold": E,
+                        "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient, bucketed under the backward pass)" if world > 1 else "")})
+
+
+WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train, "pipeline": workload_pipeline, "spatial": workload_spatial,
+             "train_kfold": workload_train_kfold}
+
+
+METRIC = "slides/sec (1000-patch WSI, UNI-dim, 20k-gene head)"
+RESNET_FLOP_PER_PATCH = 8.174e9          # SURVEY 8d: 4.087 GMAC per 224 x 224 patch
+VIS_FWD_FLOP = {1024: 5.17e9, 2048: 15.4e9}   # per slide, algorithmic (s(mean x) shortcut): 6 layers of f / projection / 2 FF products + head
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous on 127.0.0.1)."""
+    import subprocess
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def measure(name, args, rank, world, device, want_roofline=True, want_cpu=True):
+    """Build workload `name`, time it (barrier + synchronize on both sides, max over ranks), optionally profile the
+    dominant kernel and the CPU baseline.  Returns the fields of a bench line for this workload."""
+    wl = WORKLOADS[name](args, rank, world, device)
+    steps, warmup = args.steps, args.warmup
+    if steps is None:
+        # default step count: long enough that the timed region is >= ~2.5 s (a 70 ms region is not a measurement)
+        for _ in range(max(warmup, 1)):
+            wl["step"]()
+        if wl.get("flush"):
+            wl["flush"]()
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        wl["step"]()
+        if wl.get("flush"):
+            wl["flush"]()
+        barrier_sync(world)
+        est = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(est, op=torch.distributed.ReduceOp.MAX)
+        steps = int(min(2000, max(5, math.ceil(2.5 / max(float(est.item()), 1e-4)))))
+        warmup = 0 if warmup is None else max(0, warmup - 1)
+    dt = timed_region(wl["step"], steps, warmup, world, device, wl.get("flush"))
+    value = wl["slides_per_step"] * world * steps / dt
+    out = {"value": round(value, 3), "unit": "slides/s", "steps": steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / steps * 1e3, 4), "timed_region_s": round(dt, 3), "dtype": args.dtype, "config": wl["config"]}
+    recs = []
+    if want_roofline:
+        roof, recs = roofline_from_profile(wl["step"], min(steps, 3), args.dtype, name)
+        if wl.get("flush"):
+            wl["flush"]()
+        if roof is not None and name == "pipeline":
+            flop = args.patches * RESNET_FLOP_PER_PATCH + VIS_FWD_FLOP[2048]
+            roof["end_to_end"] = {"algorithmic_tflop_per_slide": round(flop / 1e12, 3),
+                                  "achieved_tflops": round(flop * value / world / 1e12, 1), "peak_tflops": PEAK[args.dtype],
+                                  "frac_of_mfma_peak": round(flop * value / world / 1e12 / PEAK[args.dtype], 4)}
+        out["roofline"] = roof
+    if want_cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = wl["cpu_baseline"]()
+    out["_recs"] = recs
+    del wl
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "vis_train"), choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: as many as make the timed region >= 2.5 s)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "pipeline"), choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=64, help="slides per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="slides per GPU per step (vis_* / train_kfold)")
+    ap.add_argument("--epochs", type=int, default=2, help="train_kfold workload: epochs per fold")
     ap.add_argument("--slides", type=int, default=8, help="pipeline workload: slides per GPU per step")
     ap.add_argument("--patches", type=int, default=1000, help="pipeline workload: patches per slide")
     ap.add_argument("--sub-batch", type=int, default=500, help="pipeline workload: patches per ResNet launch group")
@@ -355,11 +503,15 @@ def main():
     ap.add_argument("--no-stream", action="store_true", help="pipeline workload: finish every step's slides before the next step starts")
     ap.add_argument("--from-host", action="store_true", help="pipeline workload: upload the patches from pinned host memory every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the secondary measurements")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     rank, world, local = dist_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself when no launcher is present)")
     _lib.require_gpu()
     # SQ_BENCH_SHARE_GPU=1 (debugging aid for 1-GPU boxes): every rank uses cuda:0 and the collectives go through
     # gloo -- exercises the multi-process control flow (rendezvous, bucketed all-reduce, barriers), not RCCL
@@ -372,28 +524,44 @@ def main():
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=device)
+        got = torch.distributed.get_world_size()
+        if got != args.gpus:
+            raise SystemExit(f"process group has {got} ranks, --gpus asked for {args.gpus}")
+        if rank == 0:
+            print(f"bench: {got} ranks joined the {'gloo (shared GPU)' if share else 'RCCL'} process group", file=sys.stderr)
 
-    wl = WORKLOADS[args.workload](args, rank, world, device)
-    dt = timed_region(wl["step"], args.steps, args.warmup, world, device, wl.get("flush"))
-    slides = wl["slides_per_step"] * world * args.steps
-    value = slides / dt
+    res = measure(args.workload, args, rank, world, device)
+    line = {"metric": METRIC, "value": res["value"], "unit": "slides/s", "n_gpus": world, "steps": res["steps"],
+            "warmup": res["warmup"], "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": res["config"],
+            "roofline": res.get("roofline"), "cpu_baseline": res.get("cpu_baseline"), "timed_region_s": res["timed_region_s"]}
 
-    roof, recs = roofline_from_profile(wl["step"], min(args.steps, 5), args.dtype, args.workload)
-    if wl.get("flush"):
-        wl["flush"]()
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = wl["cpu_baseline"]()
+    # secondary measurements of the default run (N = 1): the PCIe-inclusive twin, BASELINE config 2, the fp32 parity
+    # mode.  Each runs in a fresh process (same script, same timing rules): a process that has already created one
+    # workload's helper streams maps later streams onto the same few hardware queues, which serialises what the
+    # next workload wants to overlap (measured: from-host 41 instead of 53 slides/s, vis_train 10.5 instead of 3.6 ms).
+    if args.workload == "pipeline" and args.dtype == "bf16" and not args.from_host and world == 1 and not args.no_secondary:
+        import subprocess
+        sec = {}
+        for key, extra in (("pipeline_from_pinned_host", ["--workload", "pipeline", "--from-host"]),
+                           ("vis_train_bf16", ["--workload", "vis_train"]),
+                           ("pipeline_fp32_parity_mode", ["--workload", "pipeline", "--dtype", "fp32", "--slides", "2", "--sub-batch", "250"])):
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-secondary", "--no-cpu-baseline", "--warmup", str(args.warmup)] + extra
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                last = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not last:
+                    raise RuntimeError((r.stderr or r.stdout)[-400:])
+                d = json.loads(last[-1])
+                sec[key] = {k: d[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "config", "roofline")}
+            except Exception as e:                      # a secondary failure must not cost the headline line
+                sec[key] = {"error": f"{type(e).__name__}: {e}"}
+        line["secondary"] = sec
 
     if rank == 0:
-        line = {"metric": "slides/sec (1000-patch WSI, UNI-dim, 20k-gene head)", "value": round(value, 3),
-                "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": wl["config"],
-                "roofline": roof, "cpu_baseline": cpu}
         if os.environ.get("SQ_BENCH_KERNELS"):
             with open(os.environ["SQ_BENCH_KERNELS"], "w") as f:
-                json.dump(sorted(recs, key=lambda r: -r["total_ms"]), f, indent=1)
+                json.dump(sorted(res["_recs"], key=lambda r: -r["total_ms"]), f, indent=1)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

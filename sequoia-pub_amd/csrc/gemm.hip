@@ -20,9 +20,12 @@
 #include "gemm_epi.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 bool sq_gemm256_eligible(const GemmArgs& a, int dtype);
 int sq_launch_gemm256(const GemmArgs& a, hipStream_t stream);
+bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype);
+int sq_launch_gemm_ring(const GemmArgs& a, hipStream_t stream);
 
 namespace {
 
@@ -510,7 +513,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return SQ_OK;
 }
 
-int g_force_tile = 0, g_dbg = 0, g_force_split = 0, g_use256 = -1;
+int g_force_tile = 0, g_dbg = 0, g_force_split = 0, g_use256 = -1, g_use_ring = -1;
 }
 extern int g_tn_force_split;
 namespace {
@@ -546,6 +549,10 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
     }
     if (g_force_split > 0 && a.splitk_ws && a.N % 8 == 0) a.splitk = g_force_split;
     if constexpr (sizeof(T) == 2) {
+        // long-K products with enough 256 x 128 tiles: three-stage ring kernel (gemm_ring.hip); SQ_GEMM_RING=0 turns it off
+        if (g_use_ring < 0) { const char* e = getenv("SQ_GEMM_RING"); g_use_ring = (e && e[0] == '0') ? 0 : 1; }
+        if (a.splitk == 1 && (g_force_tile == 33 || (g_force_tile == 0 && g_use_ring && sq_gemm_ring_eligible(a, SQ_BF16))) && a.N % 8 == 0)
+            return sq_launch_gemm_ring(a, stream);
         if (g_use256 < 0) g_use256 = sq_env_flag("SQ_GEMM256") ? 1 : 0;      // opt-in, see gemm256.hip
         if ((g_force_tile == 44 || (g_force_tile == 0 && g_use256)) && a.splitk == 1 && sq_gemm256_eligible(a, SQ_BF16)) return sq_launch_gemm256(a, stream);
     }
@@ -564,6 +571,7 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 1) g_dbg = value;
     else if (key == 2) g_force_split = value;
     else if (key == 5) g_use256 = value;
+    else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
     else return SQ_ERR_ARG;
     return SQ_OK;

@@ -303,8 +303,9 @@ def train(model, dataloaders, optimizer=None, accelerator=None,
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if save_dir is not None and not os.path.exists(save_dir) and rank == 0:
         os.mkdir(save_dir)
-    # vit.py:124: `if split:` -- fold 0 (and None) get no suffix
-    save_path = os.path.join(save_dir, f'model_best_{split}.pt' if split else 'model_best.pt')
+    # vit.py:124: `if split:` -- fold 0 (and None) get no suffix.  save_dir=None (not a reference mode): the policy runs
+    # but no checkpoint file is written (benchmarks)
+    save_path = None if save_dir is None else os.path.join(save_dir, f'model_best_{split}.pt' if split else 'model_best.pt')
 
     fused = FusedTrainStep(model, lr=lr, world_size=world, metrics=True) if optimizer is None else None
     dev = model.flat.device
@@ -355,7 +356,7 @@ def train(model, dataloaders, optimizer=None, accelerator=None,
                 print(f'Epoch {epoch}: {phase} loss {L} mae {A}')
             if phase in observing:
                 for why in policy.observe(L, S):
-                    if rank == 0:
+                    if rank == 0 and save_path is not None:
                         torch.save(model.state_dict(), save_path)
                         if why == "score":
                             print(f'Saved model on loss+corr at epoch {epoch} of better score and loss within {delta} of optimal loss')

@@ -393,8 +393,44 @@ def gold_kfold():
     print("kfold:", len(cases), "cases")
 
 
+def gold_pipeline():
+    """BASELINE config 3 end to end on ONE full-size slide with the reference's own pieces: src/resnet.py resnet50
+    forward_extract on 1000 uint8 patches of 224 x 224 (batch-1 arithmetic, run here in batches of 50), scikit-learn
+    KMeans(100, random_state=0) + the cluster means of kmean_features.py:99-105, src/tformer_lin.py ViS(D=2048)
+    forward.  Weights by seed recipe (oracle init functions) + checksums."""
+    from sklearn.cluster import KMeans
+    from oracle import resnet_oracle as ro
+    sd_r = ro.init_resnet50_state_dict(seed=99, perturb_bn=True)
+    rn = resnet50(pretrained=False)
+    full = rn.state_dict()
+    full.update(sd_r)
+    rn.load_state_dict(full)
+    rn.eval()
+    patches = synth.patches_u8(7, 1000, 224)
+    feats = []
+    with torch.no_grad():
+        for i in range(0, 1000, 50):
+            feats.append(rn.forward_extract(ro.transform_patch_u8(patches[i:i + 50])))
+    feats = torch.cat(feats).numpy()
+    km = KMeans(n_clusters=100, random_state=0).fit(feats)
+    labels = km.labels_.astype(np.int16)
+    cf = np.stack([feats[labels == j].mean(axis=0) for j in range(100)]).astype(np.float32)
+    cfg = dict(num_outputs=20820, input_dim=2048, depth=6, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd_v = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=31), seed=32)
+    model = ViS(**cfg, num_clusters=100, device="cpu")
+    model.load_state_dict(sd_v)
+    with torch.no_grad():
+        pred = model(torch.from_numpy(cf)[None])[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "pipeline_slide.npz"), labels=labels, n_iter=np.array(km.n_iter_),
+                        feat_rowsum=feats.sum(1).astype(np.float64), feat_probe=feats[::64].copy(),
+                        cluster_features_rowsum=cf.sum(1).astype(np.float64), pred=pred,
+                        resnet_checksum=checksum(sd_r), vis_checksum=checksum(sd_v),
+                        sklearn_version=np.array(__import__("sklearn").__version__))
+    print("pipeline: n_iter", km.n_iter_, "pred mean |.|", float(np.abs(pred).mean()), "clusters min size", int(np.bincount(labels).min()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats", "early_stop", "kfold"]
+    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats", "early_stop", "kfold", "pipeline"]
     if "vit_tiny" in which:
         gold_vit_tiny()
     if "vis_tiny" in which:
@@ -413,3 +449,5 @@ if __name__ == "__main__":
         gold_early_stop()
     if "kfold" in which:
         gold_kfold()
+    if "pipeline" in which:
+        gold_pipeline()

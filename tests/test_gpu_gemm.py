@@ -155,3 +155,30 @@ def test_256_tile_variant_matches_default_tile(M, N, K):
     ref = torch.relu(A.float() @ W.float().T + bias + res.float())
     assert rel_err(outs[1].cpu(), ref.cpu()) < 1e-2
     assert torch.equal(outs[0], outs[1])            # same K order and the same epilogue arithmetic -> same bits
+
+
+@pytest.mark.parametrize("M,N,K", [(70000, 256, 1024), (65536 + 77, 128, 576)])
+def test_ring_variant_matches_default_tile(M, N, K):
+    """The three-stage 256 x 128 ring kernel (gemm_ring.hip) walks K in the same order with the same MFMA as the
+    128 x 128 kernel: identical bits, including a ragged last M tile, with bias + bf16 residual + ReLU."""
+    _lib.require_gpu()
+    lib = _lib.lib()
+    lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    outs = []
+    for tile in (22, 33):
+        lib.sq_dbg_set(0, tile)
+        C = torch.empty(M, N, device="cuda")
+        _lib.check(lib.sq_linear(_lib.SQ_BF16, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(b), _lib.ptr(R), N, _lib.SQ_BF16, 2, _lib.ptr(C), 0, N, M, N, K,
+                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        outs.append(C)
+    lib.sq_dbg_set(0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.relu(A.float() @ W.float().T + b + R.float())
+    assert float((outs[1] - ref).abs().max() / ref.abs().max()) < 2e-2

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import rel_err
+from gpu_util import assert_allclose_rel, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -187,6 +187,41 @@ def test_full_size_grads_vs_oracle(mode, tol):
             worst = (k, e)
     print(f"full-size grads {mode}: worst per-tensor rel err {worst[1]:.3e} at {worst[0]}; loss {float(loss):.5f} vs {float(loss_ref):.5f}")
     assert worst[1] < tol, worst
+
+
+def test_full_size_batch64_bf16_step_vs_oracle():
+    """Exactly what bench.py's vis_train workload times -- the BASELINE config-2 model, batch 64, bf16 mode, forward +
+    MSE + backward -- against CPU fp32 autograd: loss, predictions and a subset of gradient tensors of every layer
+    (all of layer 0 and of the head, projection / FF / one mixer of the others)."""
+    _lib.require_gpu()
+    cfg = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=99), seed=5)
+    B = 64
+    x = torch.from_numpy(synth.cluster_tokens(99, B, 1024))
+    y = torch.from_numpy(synth.rna_targets(7, B))
+    torch.set_num_threads(min(32, os.cpu_count()))
+    loss_ref, pred_ref, grads_ref = vis_oracle.vis_loss_and_grads(sd, x, y)
+    m = ViS(**cfg, device="cuda:0", compute_dtype="bf16")
+    m.load_state_dict(sd)
+    m.to("cuda:0")
+    pred = m._run_forward(x.cuda(), save=True)
+    loss, gpred = sq_train.mse_loss_grad(m, pred, y.cuda())
+    gflat, _ = sq_train.vis_backward(m, gpred, B, False)
+    gv = m.grad_views(gflat)
+    e_pred = rel_err(pred.cpu().numpy(), pred_ref.detach().numpy())
+    assert_allclose_rel(pred.cpu().numpy(), pred_ref.detach().numpy(), 2e-2, "bf16 predictions at B=64")
+    keys = [k for k in grads_ref if k.startswith("transformer.layers.0.") or k.startswith("linear_head") or k == "pos_emb1D"
+            or ".mixers.7." in k or ".projection." in k or ".1.net." in k]
+    assert len(keys) > 100
+    worst = ("", 0.0)
+    for k in keys:
+        e = rel_err(gv[k].cpu().numpy(), grads_ref[k].numpy())
+        if e > worst[1]:
+            worst = (k, e)
+    print(f"B=64 bf16 step: pred rel err {e_pred:.3e}; loss {float(loss):.5f} vs {float(loss_ref):.5f}; "
+          f"worst of {len(keys)} gradient tensors {worst[1]:.3e} at {worst[0]}")
+    assert e_pred < 2e-2 and abs(float(loss) - float(loss_ref)) < 2e-3 * float(loss_ref)
+    assert worst[1] < 8e-2, worst
 
 
 def test_helper_streams_do_not_change_results(monkeypatch):
