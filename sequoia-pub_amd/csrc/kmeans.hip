@@ -21,6 +21,7 @@ namespace {
 constexpr int KM_THREADS = 1024;
 constexpr int KM_MAX_TRIALS = 8;
 constexpr int KM_MAX_K = 256;
+constexpr int KM_DOT_SLICES = 8;        // K slices of the centre x point products
 
 struct KmState {          // per slide, device memory
     int iter;             // Lloyd iterations run
@@ -102,26 +103,66 @@ __device__ __forceinline__ void block_reduce_sum_n_int(int (&v)[T], int* sh /*[1
 // ------------------------------------------------------------------------------------------
 // 1. centring + tolerance
 // ------------------------------------------------------------------------------------------
-// thread = column: rows added in index order (numpy's axis-0 reduction order), fp32
-__global__ void km_center_kernel(const float* __restrict__ X, float* __restrict__ Xc, double* __restrict__ colvar, int n, int D) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+// Column means in numpy's axis-0 order (rows added one after the other into an fp32 accumulator), X - mean in fp32,
+// and the per-column variance the stop tolerance is built from (fp64).
+// A block owns 64 columns.  Its 256 threads stream 128-row x 64-column tiles into LDS with 32 loads in flight per
+// thread (the old thread-per-column loop had ONE dependent load in flight: 1.75 ms for 8 MB); the order-sensitive
+// fp32 sum is then taken by one wave from LDS, row after row.  The fp64 moments only feed `tol`: every thread sums
+// its own rows, the four row-lanes of a column are combined in a fixed order.
+constexpr int KC_ROWS = 128, KC_COLS = 64;
+__global__ __launch_bounds__(256) void km_center_kernel(const float* __restrict__ X, float* __restrict__ Xc, double* __restrict__ colvar, int n, int D) {
+    __shared__ float tile[KC_ROWS][KC_COLS];
+    __shared__ double part[4][KC_COLS];
+    __shared__ float mean_s[KC_COLS];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;        // column inside the block, row-lane 0..3
+    const int d = blockIdx.x * KC_COLS + col;
+    const bool dok = d < D;
     const size_t base = (size_t)blockIdx.y * n * D;
-    if (d >= D) return;
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc += X[base + (size_t)i * D + d];
-    const float mean = acc / (float)n;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const float x = X[base + (size_t)i * D + d];
-        Xc[base + (size_t)i * D + d] = x - mean;
-        s += (double)x;
+    float acc = 0.f;                                                 // wave 0 only: the fp32 column sum, rows in order
+    double s64 = 0.0;
+    for (int r0 = 0; r0 < n; r0 += KC_ROWS) {
+        float v[KC_ROWS / 4];
+#pragma unroll
+        for (int u = 0; u < KC_ROWS / 4; ++u) {
+            const int r = r0 + 4 * u + rl;
+            v[u] = (dok && r < n) ? X[base + (size_t)r * D + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < KC_ROWS / 4; ++u) { tile[4 * u + rl][col] = v[u]; s64 += (double)v[u]; }
+        __syncthreads();
+        if (rl == 0) {
+            const int lim = min(KC_ROWS, n - r0);
+            for (int r = 0; r < lim; ++r) acc += tile[r][col];
+        }
+        __syncthreads();
     }
-    const double m64 = s / n;
-    for (int i = 0; i < n; ++i) {
-        const double t = (double)X[base + (size_t)i * D + d] - m64;
-        q += t * t;
+    part[rl][col] = s64;
+    if (rl == 0) mean_s[col] = acc / (float)n;
+    __syncthreads();
+    const float mean = mean_s[col];
+    const double m64 = (((part[0][col] + part[1][col]) + part[2][col]) + part[3][col]) / n;
+    __syncthreads();
+    double q = 0.0;
+    for (int r0 = 0; r0 < n; r0 += KC_ROWS) {
+        float v[KC_ROWS / 4];
+#pragma unroll
+        for (int u = 0; u < KC_ROWS / 4; ++u) {
+            const int r = r0 + 4 * u + rl;
+            v[u] = (dok && r < n) ? X[base + (size_t)r * D + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < KC_ROWS / 4; ++u) {
+            const int r = r0 + 4 * u + rl;
+            if (dok && r < n) {
+                Xc[base + (size_t)r * D + d] = v[u] - mean;
+                const double t = (double)v[u] - m64;
+                q += t * t;
+            }
+        }
     }
-    colvar[(size_t)blockIdx.y * D + d] = q / n;
+    part[rl][col] = q;
+    __syncthreads();
+    if (rl == 0 && dok) colvar[(size_t)blockIdx.y * D + d] = (((part[0][col] + part[1][col]) + part[2][col]) + part[3][col]) / n;
 }
 
 __global__ void km_tol_kernel(const double* __restrict__ colvar, KmState* __restrict__ st, int D, double tol_rel) {
@@ -140,12 +181,18 @@ __global__ void km_tol_kernel(const double* __restrict__ colvar, KmState* __rest
 // 2. fp64 MFMA GEMM with fp32 operands:  C[M,N] (f64) = A[M,K] . B[N,K]^T   (batched over slides)
 //    block 64x64, 4 waves x (2x2 tiles of 16x16), K-chunk 32 staged in LDS as [k][row] doubles
 // ------------------------------------------------------------------------------------------
+// ksl > 1: the contraction is cut into ksl slices (grid z = slide * ksl + slice), slice partials land in consecutive
+// C planes and the consumer adds them in slice order (short products -- 100 centres x 1000 points -- otherwise run on
+// 32 blocks with 64 dependent K steps each).
 __global__ __launch_bounds__(256) void km_dgemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                           double* __restrict__ C, int M, int N, int K, long long sA,
-                                                          long long sB, long long sC) {
+                                                          long long sB, long long sC, int ksl) {
     __shared__ double sa[32][64 + 2];
     __shared__ double sb[32][64 + 2];
-    A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC;
+    const int slide = blockIdx.z / ksl, slice = blockIdx.z - slide * ksl;
+    A += (long long)slide * sA; B += (long long)slide * sB; C += (long long)blockIdx.z * sC;
+    const int kper = ((K + ksl - 1) / ksl + 31) / 32 * 32;
+    const int k_lo = slice * kper, k_hi = min(K, k_lo + kper);
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -156,13 +203,13 @@ __global__ __launch_bounds__(256) void km_dgemm_nt_kernel(const float* __restric
         for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
     // loader: thread -> (row = tid / 4 within 64, k4 = tid % 4 ... two passes of 16 k each)
     const int lrow = tid >> 2, lk = (tid & 3) * 4;
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int kk = k0 + half * 16 + lk;
             float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (m0 + lrow < M && kk < K) va = *reinterpret_cast<const float4*>(A + (size_t)(m0 + lrow) * K + kk);
-            if (n0 + lrow < N && kk < K) vb = *reinterpret_cast<const float4*>(B + (size_t)(n0 + lrow) * K + kk);
+            if (m0 + lrow < M && kk < k_hi) va = *reinterpret_cast<const float4*>(A + (size_t)(m0 + lrow) * K + kk);
+            if (n0 + lrow < N && kk < k_hi) vb = *reinterpret_cast<const float4*>(B + (size_t)(n0 + lrow) * K + kk);
             const int kr = half * 16 + lk;
             sa[kr + 0][lrow] = va.x; sa[kr + 1][lrow] = va.y; sa[kr + 2][lrow] = va.z; sa[kr + 3][lrow] = va.w;
             sb[kr + 0][lrow] = vb.x; sb[kr + 1][lrow] = vb.y; sb[kr + 2][lrow] = vb.z; sb[kr + 3][lrow] = vb.w;
@@ -208,15 +255,20 @@ __device__ __forceinline__ float seed_dist(const double* G, int n, int c, int j,
     return f > 0.f ? f : 0.f;
 }
 
+// One step = scan -> candidates -> candidate potentials -> choice, i.e. three block-wide exchanges and ONE round of
+// dependent global loads (the candidates' rows of G).  The exchanges go through LDS arrays that alternate with the
+// step parity, so each costs a single barrier; the candidate distances stay in registers and the winner's are reused
+// for the `closest` update (no second read of G).  Arithmetic (scan association, reduction orders) is unchanged from
+// the first version of this kernel, results are bit-identical.
 template <int PTS>   // points per thread (n <= PTS * blockDim.x)
 __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __restrict__ Gall, const double* __restrict__ uniforms,
                                                              int first, int n, int k, int trials, int* __restrict__ seeds) {
-    __shared__ double sh[16 * KM_MAX_TRIALS];
-    __shared__ int shi[16 * KM_MAX_TRIALS];
-    __shared__ double scan_w[16];
+    __shared__ double sh[2][16 * KM_MAX_TRIALS];
+    __shared__ int shi[2][16 * KM_MAX_TRIALS];
+    __shared__ double scan_w[2][16];
     const double* G = Gall + (size_t)blockIdx.x * n * n;
     int* out = seeds + (size_t)blockIdx.x * k;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
 
     // thread owns the CONTIGUOUS points [tid*PTS, tid*PTS+PTS) so the scan is a plain blocked scan
     float closest[PTS];
@@ -227,13 +279,22 @@ __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __res
         nrm[q] = j < n ? G[(size_t)j * n + j] : 0.0;
         closest[q] = j < n ? seed_dist(G, n, first, j, nrm[q]) : 0.f;
     }
-    double part = 0.0;
+    float pot;
+    {
+        double part = 0.0;
 #pragma unroll
-    for (int q = 0; q < PTS; ++q) part += (double)closest[q];
-    float pot = (float)block_reduce_sum(part, sh);
+        for (int q = 0; q < PTS; ++q) part += (double)closest[q];
+        part = wave_sum_f64(part);
+        if (lane == 0) sh[1][wv] = part;
+        __syncthreads();
+        double r = 0.0;
+        for (int i = 0; i < nw; ++i) r += sh[1][i];
+        pot = (float)r;
+    }
     if (tid == 0) out[0] = first;
 
     for (int c = 1; c < k; ++c) {
+        const int par = c & 1;
         // stable_cumsum (fp64) of closest: per-thread serial, wave scan, block scan
         double run = 0.0, incl[PTS];
 #pragma unroll
@@ -244,29 +305,36 @@ __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __res
             const double t = __shfl_up(wscan, o, 64);
             if (lane >= o) wscan += t;
         }
-        __syncthreads();
-        if (lane == 63) scan_w[wv] = wscan;
+        if (lane == 63) scan_w[par][wv] = wscan;
         __syncthreads();
         double woff = 0.0;
-        for (int i = 0; i < wv; ++i) woff += scan_w[i];
+        for (int i = 0; i < wv; ++i) woff += scan_w[par][i];
         const double excl = woff + wscan - run;          // sum of everything before this thread's points
         // candidates: searchsorted(cumsum, u * pot, side='left') = #{cum < value}, clipped to n-1 (all trials at once)
-        int cnt[KM_MAX_TRIALS];
 #pragma unroll
         for (int t = 0; t < KM_MAX_TRIALS; ++t) {
-            cnt[t] = 0;
             if (t < trials) {
                 const double rv = uniforms[(size_t)(c - 1) * trials + t] * (double)pot;
+                int cnt = 0;
 #pragma unroll
                 for (int q = 0; q < PTS; ++q)
-                    if (tid * PTS + q < n && excl + incl[q] < rv) ++cnt[t];
+                    cnt += __popcll(__ballot(tid * PTS + q < n && excl + incl[q] < rv));
+                if (lane == 0) shi[par][wv * KM_MAX_TRIALS + t] = cnt;
             }
         }
-        block_reduce_sum_n_int<KM_MAX_TRIALS>(cnt, shi);
+        __syncthreads();
         int cand[KM_MAX_TRIALS];
+        double cn[KM_MAX_TRIALS];                        // |x_cand|^2 = G[cand][cand]
 #pragma unroll
-        for (int t = 0; t < KM_MAX_TRIALS; ++t) cand[t] = cnt[t] > n - 1 ? n - 1 : cnt[t];
-        // potentials of the candidates (one pass over this thread's points for all trials)
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) {
+            int r = 0;
+            if (t < trials)
+                for (int i = 0; i < nw; ++i) r += shi[par][i * KM_MAX_TRIALS + t];
+            cand[t] = r > n - 1 ? n - 1 : r;
+            cn[t] = t < trials ? G[(size_t)cand[t] * n + cand[t]] : 0.0;
+        }
+        // distances to the candidates (one round of loads for all trials), potentials
+        float dc[KM_MAX_TRIALS][PTS];
         double p[KM_MAX_TRIALS];
 #pragma unroll
         for (int t = 0; t < KM_MAX_TRIALS; ++t) {
@@ -275,16 +343,38 @@ __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __res
 #pragma unroll
                 for (int q = 0; q < PTS; ++q) {
                     const int j = tid * PTS + q;
-                    if (j < n) p[t] += (double)fminf(closest[q], seed_dist(G, n, cand[t], j, nrm[q]));
+                    float f = 0.f;
+                    if (j < n) {
+                        // pairwise.py:647-651: d = -2 X.Y^T; d += XX; d += YY; cast fp32; max(., 0)
+                        double dd = -2.0 * G[(size_t)cand[t] * n + j];
+                        dd += cn[t];
+                        dd += nrm[q];
+                        f = (float)dd;
+                        f = f > 0.f ? f : 0.f;
+                        p[t] += (double)fminf(closest[q], f);
+                    }
+                    dc[t][q] = f;
                 }
             }
         }
-        block_reduce_sum_n<KM_MAX_TRIALS>(p, sh);
-        float best_pot = (float)p[0];
+#pragma unroll
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) p[t] = wave_sum_f64(p[t]);
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < KM_MAX_TRIALS; ++t) sh[par][wv * KM_MAX_TRIALS + t] = p[t];
+        }
+        __syncthreads();
+        float best_pot = 0.f;
         int best_t = 0;
 #pragma unroll
-        for (int t = 1; t < KM_MAX_TRIALS; ++t)
-            if (t < trials && (float)p[t] < best_pot) { best_pot = (float)p[t]; best_t = t; }     // np.argmin: first minimum
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) {
+            if (t < trials) {
+                double r = 0.0;
+                for (int i = 0; i < nw; ++i) r += sh[par][i * KM_MAX_TRIALS + t];
+                const float pt = (float)r;
+                if (t == 0 || pt < best_pot) { best_pot = pt; best_t = t; }     // np.argmin: first minimum
+            }
+        }
         int chosen = cand[0];
 #pragma unroll
         for (int t = 1; t < KM_MAX_TRIALS; ++t)
@@ -292,8 +382,11 @@ __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __res
         pot = best_pot;
 #pragma unroll
         for (int q = 0; q < PTS; ++q) {
-            const int j = tid * PTS + q;
-            if (j < n) closest[q] = fminf(closest[q], seed_dist(G, n, chosen, j, nrm[q]));
+            float f = dc[0][q];
+#pragma unroll
+            for (int t = 1; t < KM_MAX_TRIALS; ++t)
+                if (t == best_t) f = dc[t][q];
+            if (tid * PTS + q < n) closest[q] = fminf(closest[q], f);
         }
         if (tid == 0) out[c] = chosen;
     }
@@ -310,30 +403,76 @@ __global__ void km_gather_centers_kernel(const float* __restrict__ Xc, const int
 // ------------------------------------------------------------------------------------------
 // 4. Lloyd iteration pieces (every kernel returns at once for slides that are done)
 // ------------------------------------------------------------------------------------------
-// labels[j] = argmin_c (|c|^2 - 2 x_j.c), strict '<' (first minimum); dots from the fp64 GEMM
-__global__ void km_assign_kernel(const double* __restrict__ dots, const float* __restrict__ centers, int* __restrict__ labels,
-                                 const KmState* __restrict__ st, int n, int D, int k, int force) {
+// |c|^2 in fp64, one wave per centre (lanes stride the row, butterfly sum): its own launch, because inside the assign
+// kernel every block recomputed all k norms with 25 dependent row walks per wave (0.25 ms of a 0.3 ms kernel)
+__global__ __launch_bounds__(64) void km_center_norms_kernel(const float* __restrict__ centers, double* __restrict__ cnorm,
+                                                             const KmState* __restrict__ st, int D, int k, int force) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    if (st[s].done && !force) return;
+    const float* cr = centers + ((size_t)s * k + c) * D;
+    double a = 0.0;
+    int d = threadIdx.x;
+    for (; d + 7 * 64 < D; d += 8 * 64) {          // eight loads in flight, added in the same (ascending d) order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = cr[d + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += (double)v[u] * (double)v[u];
+    }
+    for (; d < D; d += 64) a += (double)cr[d] * (double)cr[d];
+    a = wave_sum_f64(a);
+    if (threadIdx.x == 0) cnorm[(size_t)s * k + c] = a;
+}
+
+// labels[j] = argmin_c (|c|^2 - 2 x_j.c), strict '<' (first minimum); dots from the fp64 GEMM as ksl planes of
+// [k centres][n points] (a thread walks the centres of ITS point: consecutive threads read consecutive doubles)
+__global__ __launch_bounds__(256) void km_assign_kernel(const double* __restrict__ dots, const double* __restrict__ cnorm, int* __restrict__ labels,
+                                                        const KmState* __restrict__ st, int n, int D, int k, int force, int ksl) {
+    // block = 64 points x 4 centre groups (wave g walks centres [g*k/4, (g+1)*k/4) of its 64 points, five centres'
+    // loads in flight at a time); the four partial minima are merged in centre order, which keeps the first minimum
     __shared__ double cn[KM_MAX_K];
+    __shared__ double bval[4][64];
+    __shared__ int blab[4][64];
     const int s = blockIdx.y;
     if (st[s].done && !force) return;
-    for (int c = threadIdx.x >> 6; c < k; c += blockDim.x >> 6) {       // wave per centre: |c|^2 in fp64
-        const float* cr = centers + ((size_t)s * k + c) * D;
-        double a = 0.0;
-        for (int d = threadIdx.x & 63; d < D; d += 64) a += (double)cr[d] * (double)cr[d];
-        a = wave_sum_f64(a);
-        if ((threadIdx.x & 63) == 0) cn[c] = a;
-    }
+    for (int c = threadIdx.x; c < k; c += blockDim.x) cn[c] = cnorm[(size_t)s * k + c];
     __syncthreads();
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const double* dr = dots + ((size_t)s * n + j) * k;
-    double best = cn[0] - 2.0 * dr[0];
-    int lab = 0;
-    for (int c = 1; c < k; ++c) {
-        const double v = cn[c] - 2.0 * dr[c];
-        if (v < best) { best = v; lab = c; }
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int c_lo = g * k / 4, c_hi = (g + 1) * k / 4;
+    const size_t plane = (size_t)k * n;
+    const double* dr = dots + (size_t)s * ksl * plane + (j < n ? j : 0);
+    double best = 0.0;
+    int lab = -1;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 5) {
+        double dot[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int c = c0 + u < c_hi ? c0 + u : c_hi - 1;
+            double a = dr[(size_t)c * n];
+            for (int q = 1; q < ksl; ++q) a += dr[q * plane + (size_t)c * n];
+            dot[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int c = c0 + u;
+            if (c < c_hi) {
+                const double v = cn[c] - 2.0 * dot[u];
+                if (lab < 0 || v < best) { best = v; lab = c; }
+            }
+        }
     }
-    labels[(size_t)s * n + j] = lab;
+    bval[g][lane] = best;
+    blab[g][lane] = lab;
+    __syncthreads();
+    if (g == 0 && j < n) {
+        double b = bval[0][lane];
+        int l = blab[0][lane];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (blab[q][lane] >= 0 && (l < 0 || bval[q][lane] < b)) { b = bval[q][lane]; l = blab[q][lane]; }
+        labels[(size_t)s * n + j] = l;
+    }
 }
 
 // counting sort of point ids by label, stable in the point index: members[off[c] .. off[c+1])
@@ -372,9 +511,18 @@ __global__ void km_sums_kernel(const float* __restrict__ Xc, const int* __restri
     const int c = blockIdx.x, s = blockIdx.y;
     if (st[s].done) return;
     const int lo = offsets[(size_t)s * (k + 1) + c], hi = offsets[(size_t)s * (k + 1) + c + 1];
+    const int* mem = members + (size_t)s * n;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         double a = 0.0;
-        for (int i = lo; i < hi; ++i) a += (double)Xc[((size_t)s * n + members[(size_t)s * n + i]) * D + d];
+        int i = lo;
+        for (; i + 8 <= hi; i += 8) {              // eight gathered rows in flight, added in member (= index) order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Xc[((size_t)s * n + mem[i + u]) * D + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)v[u];
+        }
+        for (; i < hi; ++i) a += (double)Xc[((size_t)s * n + mem[i]) * D + d];
         sums[((size_t)s * k + c) * D + d] = a;
     }
 }
@@ -436,41 +584,51 @@ __global__ __launch_bounds__(KM_THREADS) void km_relocate_kernel(const float* __
     }
 }
 
-// _average_centers + _center_shift + the stop rule of _kmeans_single_lloyd; one workgroup per slide
-__global__ __launch_bounds__(KM_THREADS) void km_update_kernel(float* __restrict__ centers, const double* __restrict__ sums,
-                                                               const double* __restrict__ weights, const int* __restrict__ labels,
-                                                               int* __restrict__ labels_old, KmState* __restrict__ st, int n,
-                                                               int D, int k, int max_iter) {
+// _average_centers + _center_shift: one block per (cluster, slide) writes the new centre row into the OTHER centre
+// buffer (a cluster left empty copies the heaviest cluster's new row, so rows cannot be updated in place) and its
+// share of the squared shift; slides that are done copy their rows through, so both buffers stay valid for them.
+__global__ __launch_bounds__(256) void km_update_centers_kernel(const float* __restrict__ centers, float* __restrict__ centers_new,
+                                                                const double* __restrict__ sums, const double* __restrict__ weights,
+                                                                double* __restrict__ shift_part, const KmState* __restrict__ st,
+                                                                int D, int k) {
     __shared__ double sh[16];
-    __shared__ int shi[16];
-    __shared__ int amax;
-    const int s = blockIdx.x;
-    if (st[s].done) return;
+    __shared__ int amax_s;
+    const int c = blockIdx.x, s = blockIdx.y;
+    const float* old_row = centers + ((size_t)s * k + c) * D;
+    float* new_row = centers_new + ((size_t)s * k + c) * D;
+    if (st[s].done) {
+        for (int d = threadIdx.x; d < D; d += blockDim.x) new_row[d] = old_row[d];
+        return;
+    }
     const double* w = weights + (size_t)s * k;
     if (threadIdx.x == 0) {
         int a = 0;
-        for (int c = 1; c < k; ++c)
-            if (w[c] > w[a]) a = c;      // np.argmax: first maximum
-        amax = a;
+        for (int i = 1; i < k; ++i)
+            if (w[i] > w[a]) a = i;      // np.argmax: first maximum
+        amax_s = a;
     }
     __syncthreads();
+    const int src = w[c] > 0.0 ? c : amax_s;
+    const double ws = w[src];
+    const double* srow = sums + ((size_t)s * k + src) * D;
     double shift = 0.0;
-    for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
-        const int c = i / D, d = i - c * D;
-        const int src = w[c] > 0.0 ? c : amax;
-        const float nv = (float)(sums[((size_t)s * k + src) * D + d] / w[src]);
-        const float ov = centers[(size_t)s * k * D + i];
-        const double df = (double)nv - (double)ov;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float nv = (float)(srow[d] / ws);
+        const double df = (double)nv - (double)old_row[d];
         shift += df * df;
+        new_row[d] = nv;
     }
     shift = block_reduce_sum(shift, sh);
-    __syncthreads();
-    // write after every thread has read the old centres of the rows it needs (amax row is read by others)
-    for (int i = threadIdx.x; i < k * D; i += blockDim.x) {
-        const int c = i / D, d = i - c * D;
-        const int src = w[c] > 0.0 ? c : amax;
-        centers[(size_t)s * k * D + i] = (float)(sums[((size_t)s * k + src) * D + d] / w[src]);
-    }
+    if (threadIdx.x == 0) shift_part[(size_t)s * k + c] = shift;
+}
+
+// the stop rule of _kmeans_single_lloyd; one workgroup per slide
+__global__ __launch_bounds__(KM_THREADS) void km_finish_iter_kernel(const double* __restrict__ shift_part, const int* __restrict__ labels,
+                                                                    int* __restrict__ labels_old, KmState* __restrict__ st, int n, int k,
+                                                                    int max_iter) {
+    __shared__ int shi[16];
+    const int s = blockIdx.x;
+    if (st[s].done) return;
     int diff = 0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const int l = labels[(size_t)s * n + j];
@@ -479,6 +637,8 @@ __global__ __launch_bounds__(KM_THREADS) void km_update_kernel(float* __restrict
     }
     diff = block_reduce_sum_int(diff, shi);
     if (threadIdx.x == 0) {
+        double shift = 0.0;
+        for (int c = 0; c < k; ++c) shift += shift_part[(size_t)s * k + c];      // cluster order
         KmState& ks = st[s];
         ks.iter += 1;
         ks.shift = shift;
@@ -521,7 +681,7 @@ __global__ void km_cluster_means_kernel(const float* __restrict__ X, const int* 
 }
 
 struct KmBufs {
-    float* Xc; double* colvar; double* G; float* centers; double* dots; double* sums; double* weights; double* dist;
+    float* Xc; double* colvar; double* G; float* centers; float* centers2; double* shift_part; double* dots; double* sums; double* weights; double* dist;
     int* seeds; int* labels_old; int* members; int* offsets; int* done_count; KmState* st;
     size_t bytes;
 };
@@ -533,7 +693,9 @@ void km_bufs(int S, int n, int D, int k, char* base, KmBufs* o) {
     o->colvar = (double*)take((size_t)S * D * 8);
     o->G = (double*)take((size_t)S * n * n * 8);
     o->centers = (float*)take((size_t)S * k * D * 4);
-    o->dots = (double*)take((size_t)S * n * k * 8);
+    o->centers2 = (float*)take((size_t)S * k * D * 4);
+    o->shift_part = (double*)take((size_t)S * k * 8 * 2);      // [S][k] shift shares, then [S][k] centre norms
+    o->dots = (double*)take((size_t)S * KM_DOT_SLICES * n * k * 8);
     o->sums = (double*)take((size_t)S * k * D * 8);
     o->weights = (double*)take((size_t)S * k * 8);
     o->dist = (double*)take((size_t)S * n * 8);
@@ -572,15 +734,18 @@ extern "C" int sq_kmeans_fit(const float* X, int S, int n, int D, int k, int fir
         sq_set_error("kmeans: workspace %zu < required %zu", workspace_bytes, b.bytes);
         return SQ_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(km_center_kernel, dim3((D + 255) / 256, S), dim3(256), 0, st, X, b.Xc, b.colvar, n, D);
+    hipLaunchKernelGGL(km_center_kernel, dim3((D + KC_COLS - 1) / KC_COLS, S), dim3(256), 0, st, X, b.Xc, b.colvar, n, D);
     SQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(km_tol_kernel, dim3(S), dim3(256), 0, st, b.colvar, b.st, D, tol);
     SQ_LAUNCH_CHECK();
     // Gram matrix of the centred data (fp64)
     hipLaunchKernelGGL(km_dgemm_nt_kernel, dim3((n + 63) / 64, (n + 63) / 64, S), dim3(256), 0, st, b.Xc, b.Xc, b.G, n, n, D,
-                       (long long)n * D, (long long)n * D, (long long)n * n);
+                       (long long)n * D, (long long)n * D, (long long)n * n, 1);
     SQ_LAUNCH_CHECK();
-    if (n <= KM_THREADS)
+    const bool few_waves = !sq_env_flag("SQ_KM_SEED_1024");
+    if (n <= KM_THREADS && few_waves)       // 4 waves x 4 points per thread: cheaper barriers and wave exchanges than 16 waves x 1
+        hipLaunchKernelGGL(km_seed_kernel<4>, dim3(S), dim3(256), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
+    else if (n <= KM_THREADS)
         hipLaunchKernelGGL(km_seed_kernel<1>, dim3(S), dim3(KM_THREADS), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
     else if (n <= 2 * KM_THREADS)
         hipLaunchKernelGGL(km_seed_kernel<2>, dim3(S), dim3(KM_THREADS), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
@@ -592,11 +757,17 @@ extern "C" int sq_kmeans_fit(const float* X, int S, int n, int D, int k, int fir
     SQ_LAUNCH_CHECK();
     SQ_HIP_CHECK(hipMemsetAsync(b.labels_old, 0xff, (size_t)S * n * 4, st));          // labels_old = -1
 
+    float* cur = b.centers;          // centres of the iteration in flight; the update writes the other buffer
+    float* nxt = b.centers2;
+    const int ksl = D >= 32 * KM_DOT_SLICES ? KM_DOT_SLICES : 1;
     auto e_step = [&](int force) -> int {
-        hipLaunchKernelGGL(km_dgemm_nt_kernel, dim3((k + 63) / 64, (n + 63) / 64, S), dim3(256), 0, st, b.Xc, b.centers, b.dots, n, k, D,
-                           (long long)n * D, (long long)k * D, (long long)n * k);
+        // dots[slice][centre][point] = centres . points (fp64), K sliced so that the launch fills the chip
+        hipLaunchKernelGGL(km_dgemm_nt_kernel, dim3((n + 63) / 64, (k + 63) / 64, S * ksl), dim3(256), 0, st, cur, b.Xc, b.dots, k, n, D,
+                           (long long)k * D, (long long)n * D, (long long)k * n, ksl);
         SQ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(km_assign_kernel, dim3((n + 255) / 256, S), dim3(256), 0, st, b.dots, b.centers, labels, b.st, n, D, k, force);
+        hipLaunchKernelGGL(km_center_norms_kernel, dim3(k, S), dim3(64), 0, st, cur, b.shift_part + (size_t)S * k, b.st, D, k, force);
+        SQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(km_assign_kernel, dim3((n + 63) / 64, S), dim3(256), 0, st, b.dots, b.shift_part + (size_t)S * k, labels, b.st, n, D, k, force, ksl);
         SQ_LAUNCH_CHECK();
         hipLaunchKernelGGL(km_members_kernel, dim3(S), dim3(KM_THREADS), 0, st, labels, b.members, b.offsets, b.st, n, k, force);
         SQ_LAUNCH_CHECK();
@@ -609,12 +780,14 @@ extern "C" int sq_kmeans_fit(const float* X, int S, int n, int D, int k, int fir
             if (int e = e_step(0)) return e;
             hipLaunchKernelGGL(km_sums_kernel, dim3(k, S), dim3(256), 0, st, b.Xc, b.members, b.offsets, b.sums, b.st, n, D, k);
             SQ_LAUNCH_CHECK();
-            hipLaunchKernelGGL(km_relocate_kernel, dim3(S), dim3(KM_THREADS), 0, st, b.Xc, b.centers, labels, b.offsets, b.sums,
+            hipLaunchKernelGGL(km_relocate_kernel, dim3(S), dim3(KM_THREADS), 0, st, b.Xc, cur, labels, b.offsets, b.sums,
                                b.weights, b.dist, b.st, n, D, k);
             SQ_LAUNCH_CHECK();
-            hipLaunchKernelGGL(km_update_kernel, dim3(S), dim3(KM_THREADS), 0, st, b.centers, b.sums, b.weights, labels, b.labels_old,
-                               b.st, n, D, k, max_iter);
+            hipLaunchKernelGGL(km_update_centers_kernel, dim3(k, S), dim3(256), 0, st, cur, nxt, b.sums, b.weights, b.shift_part, b.st, D, k);
             SQ_LAUNCH_CHECK();
+            hipLaunchKernelGGL(km_finish_iter_kernel, dim3(S), dim3(KM_THREADS), 0, st, b.shift_part, labels, b.labels_old, b.st, n, k, max_iter);
+            SQ_LAUNCH_CHECK();
+            float* t = cur; cur = nxt; nxt = t;
         }
         hipLaunchKernelGGL(km_count_done_kernel, dim3(1), dim3(64), 0, st, b.st, S, b.done_count);
         SQ_LAUNCH_CHECK();
