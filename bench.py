@@ -86,7 +86,7 @@ def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
     For the roofline the helper streams are therefore switched off during these extra steps (same kernels, same
     shapes, one at a time); the rocprofv3 summary taken the same way is profiles/r01_*_kernel_stats_serial.csv, the one
     of the overlapped timed region profiles/r01_*_kernel_stats.csv."""
-    serial = {"SQ_BWD_ONE_STREAM": "1", "SQ_FWD_ONE_STREAM": "1", "SQ_RESNET_STREAMS": "1"}
+    serial = {"SQ_BWD_ONE_STREAM": "1", "SQ_FWD_ONE_STREAM": "1", "SQ_RESNET_STREAMS": "1", "SQ_SPATIAL_STREAMS": "1"}
     saved = {k: os.environ.get(k) for k in serial}
     os.environ.update(serial)
     try:

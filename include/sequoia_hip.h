@@ -89,6 +89,18 @@ int sq_vis_forward(const sq_vis_config* cfg, int dtype, const float* params, con
                    float* out, int batch, int save_for_backward, void* workspace, size_t workspace_bytes,
                    sq_stream_t stream);
 
+/* sq_vis_forward with two options the sliding-window path (spatial_vis/visualize.py:35-102) uses:
+ *  - gather: instead of x, give gather_src f32 [gather_rows, D] (the tile-feature cache) and gather_idx int32
+ *    [B, num_clusters]; token (b, t) is row gather_idx[b, t] of the cache, a negative index is a zero row (the
+ *    zero padding of visualize.py:72-75) -- the [B, 100, D] window batch is never materialised;
+ *  - head_in: instead of out, receive the linear head's INPUT LayerNorm(mean_tokens X) as f32 [B, D]; the head is
+ *    linear, so the per-tile mean over windows (visualize.py:97-100) can be taken on these D-vectors and the head
+ *    applied once per tile (sq_linear) instead of materialising [n_windows, G] predictions.
+ * Exactly one of (x | gather_src + gather_idx) and exactly one of (out | head_in) must be given. */
+int sq_vis_forward_ex(const sq_vis_config* cfg, int dtype, const float* params, const void* params_lp, const float* x,
+                      const float* gather_src, const int32_t* gather_idx, int gather_rows, float* out, float* head_in,
+                      int batch, int save_for_backward, void* workspace, size_t workspace_bytes, sq_stream_t stream);
+
 /* Backward of ViS.forward -- replaces torch autograd over tformer_lin.py in the training loop
  * (src/vit.py:163-180 `loss.backward()`).  grad_out f32 [B, G]; grad_params: flat f32 buffer with
  * the parameter layout, fully overwritten; grad_x f32 [B, num_clusters, D] or NULL.

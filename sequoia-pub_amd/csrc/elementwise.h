@@ -5,6 +5,7 @@
 // X[b,n,:] = x[b,n,:] + pos[n,:]   (tformer_lin.py:100); optional bf16 copy
 int sq_k_add_pos(const float* x, const float* pos, float* X, bf16_t* Xh, int B, int N, int D, hipStream_t s);
 // out[b,:] = mean_n X[b,n,:]       (tformer_lin.py:22 via s(mean x), :103); optional bf16 copy
+int sq_k_add_pos_gather(const float* src, const int32_t* idx, const float* pos, float* X, bf16_t* Xh, int B, int N, int D, hipStream_t s);
 int sq_k_token_mean(const float* X, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s);
 // y = LayerNorm_D(x) * g + b       (rows of length D <= 4096, eps 1e-5); out f32 or bf16; optional mean/rstd save
 int sq_k_ln_rows(const float* x, const float* g, const float* b, void* y, int out_dtype, int R, int D,

@@ -15,6 +15,22 @@ __global__ void add_pos_kernel(const float4* __restrict__ x, const float4* __res
     }
 }
 
+// X[b, t, :] = src[idx[b, t], :] + pos[t, :]  (idx < 0: a zero row -- window padding, spatial_vis/visualize.py:72-75):
+// the [B, N, D] input of a window batch is never materialised, rows come straight from the tile-feature cache
+__global__ void add_pos_gather_kernel(const float4* __restrict__ src, const int32_t* __restrict__ idx, const float4* __restrict__ pos,
+                                      float4* __restrict__ X, uint2* __restrict__ Xh, uint32_t total4, uint32_t nd4, uint32_t d4) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+        const uint32_t row = i / d4, col = i - row * d4;
+        const int32_t r = idx[row];
+        const float4 p = pos[i % nd4];
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= 0) a = src[(size_t)r * d4 + col];
+        const float4 v = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        X[i] = v;
+        if (Xh) Xh[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+}
+
 // thread = (b, d4, quarter of the tokens); quarters combined through LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void token_mean_kernel(const float4* __restrict__ X, float4* __restrict__ out, uint2* __restrict__ outh,
                                                          int B, int N, int D4) {
@@ -216,6 +232,16 @@ int sq_k_add_pos(const float* x, const float* pos, float* X, bf16_t* Xh, int B, 
     const uint32_t total4 = (uint32_t)((size_t)B * N * D / 4), nd4 = (uint32_t)((size_t)N * D / 4);
     hipLaunchKernelGGL(add_pos_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, s, (const float4*)x, (const float4*)pos,
                        (float4*)X, (uint2*)Xh, total4, nd4);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_add_pos_gather(const float* src, const int32_t* idx, const float* pos, float* X, bf16_t* Xh, int B, int N, int D, hipStream_t s) {
+    SQ_REQUIRE(D % 4 == 0, "add_pos: D=%d must be a multiple of 4", D);
+    SQ_REQUIRE((size_t)B * N * D / 4 < (1ull << 31), "add_pos: tensor too large for 32-bit indexing");
+    const uint32_t total4 = (uint32_t)((size_t)B * N * D / 4), nd4 = (uint32_t)((size_t)N * D / 4);
+    hipLaunchKernelGGL(add_pos_gather_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, s, (const float4*)src, idx, (const float4*)pos,
+                       (float4*)X, (uint2*)Xh, total4, nd4, (uint32_t)(D / 4));
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }

@@ -292,6 +292,9 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs p) {
 // tiles to keep 256 CUs (one block each) busy for at least ~2 rounds
 bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype) {
     if (dtype != SQ_BF16 || a.splitk != 1 || a.ln64_g) return false;
+    // only the epilogues the prefetching fast path covers (bias, residual, ReLU): with one block per CU nothing hides a
+    // generic epilogue, and the ViS products (GELU / extra copies / row bias) measured 2x slower here than on gemm.hip
+    if (a.rowbias || a.Cpre || a.C2 || a.gelu_grad_of || a.act == SQ_ACT_GELU) return false;
     static int min_tiles = -1, min_k = -1;
     if (min_tiles < 0) {
         const char* e = getenv("SQ_GEMM_RING_MIN_TILES");

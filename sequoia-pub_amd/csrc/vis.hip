@@ -120,10 +120,20 @@ struct Lin {      // one nn.Linear on the flat parameter buffer
 
 extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* params, const void* params_lp, const float* x,
                               float* out, int B, int save, void* workspace, size_t workspace_bytes, sq_stream_t stream_) {
+    SQ_REQUIRE(x && out, "vis_forward: null pointer");
+    return sq_vis_forward_ex(c, dtype, params, params_lp, x, nullptr, nullptr, 0, out, nullptr, B, save, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float* params, const void* params_lp, const float* x,
+                                 const float* gather_src, const int32_t* gather_idx, int gather_rows, float* out, float* head_in,
+                                 int B, int save, void* workspace, size_t workspace_bytes, sq_stream_t stream_) {
     if (int e = check_cfg(c)) return e;
     hipStream_t st = (hipStream_t)stream_;
     SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16, "vis_forward: dtype %d", dtype);
-    SQ_REQUIRE(params && x && out && workspace, "vis_forward: null pointer");
+    SQ_REQUIRE(params && workspace, "vis_forward: null pointer");
+    SQ_REQUIRE((x != nullptr) != (gather_src != nullptr && gather_idx != nullptr), "vis_forward: give either x or (gather_src, gather_idx)");
+    SQ_REQUIRE(x || gather_rows >= 1, "vis_forward: gather_rows=%d", gather_rows);
+    SQ_REQUIRE((out != nullptr) != (head_in != nullptr), "vis_forward: give either out (predictions) or head_in (the head's input)");
     SQ_REQUIRE(dtype == SQ_F32 || params_lp, "vis_forward: bf16 mode needs the bf16 parameter shadow");
     SQ_REQUIRE(B >= 1, "vis_forward: batch=%d", B);
     sq_vis_layout lay;
@@ -143,7 +153,11 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
     auto Wrem = [&](int64_t off) { return (size_t)(lay.total - off) * es; };
     auto Pf = [&](int64_t off) { return params + off; };
 
-    if (int e = sq_k_add_pos(x, Pf(lay.pos), w.Xin[0], lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
+    if (x) {
+        if (int e = sq_k_add_pos(x, Pf(lay.pos), w.Xin[0], lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
+    } else {
+        if (int e = sq_k_add_pos_gather(gather_src, gather_idx, Pf(lay.pos), w.Xin[0], lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
+    }
     SqSideStream* fs = (lp && !sq_env_flag("SQ_FWD_ONE_STREAM")) ? sq_side_stream(1, 4 * SQ_MAX_DEPTH) : nullptr;
     hipStream_t s2 = fs ? fs->stream : st;
     int ev_next = 0;
@@ -228,6 +242,8 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
     }
     const float* Xfin = w.Xin[save ? c->depth : 0];
     if (int e = sq_k_token_mean(Xfin, w.xm, nullptr, B, N, D, st)) return e;
+    if (head_in)        // the caller applies the (linear) head itself, e.g. after averaging over windows: LN output in fp32
+        return sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), head_in, SQ_F32, B, D, nullptr, nullptr, st);
     if (int e = sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), w.xn, dtype, B, D, nullptr, nullptr, st)) return e;
     {   // out = xn Wh^T + bh
         GemmArgs g; g.A = w.xn; g.lda = D; g.a_bytes = (size_t)B * D * es;

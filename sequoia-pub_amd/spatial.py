@@ -5,8 +5,11 @@ averaged over, for stride < 10) every tile of the window.
 
 Differences in HOW (not what): every tile is embedded ONCE into a feature cache (the reference re-embeds a tile
 in every window that contains it, up to 100 times); windows are enumerated with tensor ops and run through the
-model in large batches (BASELINE config 5: ~47k windows of 100 tokens).  ``literal_2d=True`` reproduces the
+model in large batches (BASELINE config 5: ~47k windows of 100 tokens) that are gathered from the cache on the fly;
+the linear head is applied once per tile, after the vote.  ``literal_2d=True`` reproduces the
 reference's 2-D input quirk (the prediction depends only on the window's first tile)."""
+import os
+
 import numpy as np
 import torch
 
@@ -62,46 +65,49 @@ def tile_window_lists(members, n_tiles, device):
 def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=False, batch_windows=1024):
     """All-gene form of visualize.py:35-102 (BASELINE config 5: per-tile 20 820-gene regression): returns
     (tile_pred f32 [n_tiles, G] with NaN for tiles no kept window covers, votes int64 [n_tiles]).
-    Window predictions stay on the device as [W, G]; the per-tile mean / last-writer rule is one sq_window_vote."""
+
+    Nothing of size [windows, 100, D] or [windows, G] exists: a window batch is gathered from the tile-feature cache
+    inside the model's first kernel (member indices, -1 = the zero padding of :72-75), the model stops in front of
+    its linear head, the per-tile mean / last-writer rule (:87-100) is applied to those D-vectors (sq_window_vote),
+    and the head runs ONCE per tile -- mean_w(head(v_w)) = head(mean_w v_w) for a linear head, so HBM sees the
+    [n_tiles, G] result once and 100x fewer head products are computed."""
     _lib.require_gpu()
     members, _ = enumerate_windows(xtf, ytf, stride)
     dev = model.flat.device
-    feats = tile_features.to(dev, torch.float32)
+    feats = tile_features.to(dev, torch.float32).contiguous()
     n_tiles, D = feats.shape
     G = model.cfg.num_outputs
     if len(members) == 0:
         return torch.full((n_tiles, G), float("nan"), device=dev), torch.zeros(n_tiles, dtype=torch.int64, device=dev)
-    feats_pad = torch.cat([feats, torch.zeros(1, D, device=dev)])               # index -1 -> zero row (padding)
     mem = torch.from_numpy(members).to(dev)
+    gather = (mem[:, 0:1].expand(-1, mem.shape[1]) if literal_2d else mem).to(torch.int32).contiguous()
+    # literal_2d: the reference feeds a 2-D [100, D] tensor and takes row 0 -> the prediction depends on the window's
+    # first tile only, replicated over the 100 positions (SURVEY 3.5)
     W = mem.shape[0]
-    win_pred = torch.empty(W, G, dtype=torch.float32, device=dev)
+    win_vec = torch.empty(W, D, dtype=torch.float32, device=dev)
     # two batches of windows in flight on two streams (own workspaces): each forward is a chain of dependent
     # launches, a second chain fills the ramp-up / store-drain phases of the first
     main = torch.cuda.current_stream(dev)
+    ns = max(1, int(os.environ.get("SQ_SPATIAL_STREAMS", "2")))
     streams = model.__dict__.setdefault("_spatial_streams", None)
-    if streams is None or streams[0].device != dev:
-        streams = model.__dict__["_spatial_streams"] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    if streams is None or streams[0].device != dev or len(streams) != ns:
+        streams = model.__dict__["_spatial_streams"] = [torch.cuda.Stream(device=dev) for _ in range(ns)]
     model._params_lp()                              # refresh the bf16 shadow on the main stream BEFORE the hand-over event:
     start = torch.cuda.Event()                      # the window streams wait on `start` only and must see the finished cast
     start.record(main)
     for i, s in enumerate(range(0, W, batch_windows)):
-        st = streams[i % 2]
+        st = streams[i % ns]
         st.wait_event(start)
         with torch.cuda.stream(st):
-            m = mem[s:s + batch_windows]
-            x = feats_pad[m]                                                    # [w, 100, D]
-            if literal_2d:
-                # reference: model(features_all) with a 2-D [100, D] tensor, then [0]  -> depends on tile 0 only
-                x = x[:, 0:1, :].expand(-1, 100, -1).contiguous()
-            win_pred[s:s + m.shape[0]] = model._run_forward(x, False, slot=i % 2)
+            win_vec[s:s + batch_windows] = model._run_head_inputs(feats, gather[s:s + batch_windows], slot=1 + i % ns)
     for st in streams:
         main.wait_stream(st)
     lists, counts = tile_window_lists(mem, n_tiles, dev)
-    out = torch.empty(n_tiles, G, dtype=torch.float32, device=dev)
+    tile_vec = torch.empty(n_tiles, D, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().sq_window_vote(_lib.ptr(win_pred), W, G, _lib.ptr(lists), n_tiles, lists.shape[1],
-                                             1 if stride == 10 else 0, float("nan"), _lib.ptr(out), _lib.stream_ptr(dev)))
-    return out, counts
+        _lib.check(_lib.lib().sq_window_vote(_lib.ptr(win_vec), W, D, _lib.ptr(lists), n_tiles, lists.shape[1],
+                                             1 if stride == 10 else 0, float("nan"), _lib.ptr(tile_vec), _lib.stream_ptr(dev)))
+    return model.apply_head(tile_vec), counts
 
 
 @torch.no_grad()

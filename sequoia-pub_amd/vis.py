@@ -297,6 +297,46 @@ class ViS(nn.Module, PyTorchModelHubMixin):
             self._saved_gen = self.__dict__.get("_saved_gen", 0) + 1
         return out
 
+    def _run_head_inputs(self, cache, members, slot=0):
+        """Sliding-window form (sq_vis_forward_ex): cache f32 [n_rows, D] on the device, members int32 [B, 100] rows of
+        the cache per window (-1 = zero padding).  Returns the linear head's input LayerNorm(mean_tokens X) f32 [B, D]
+        -- the window batch [B, 100, D] is gathered inside the first kernel and the head is left to the caller."""
+        _lib.require_gpu()
+        if self._C_FWD != "sq_vis_forward":
+            raise NotImplementedError("head inputs are implemented for ViS (the linear-attention aggregator)")
+        B, N = members.shape
+        if N != self.cfg.num_clusters or cache.shape[1] != self._dim():
+            raise ValueError(f"expected members [B, {self.cfg.num_clusters}] and a [rows, {self._dim()}] cache")
+        out = torch.empty(B, self._dim(), dtype=torch.float32, device=cache.device)
+        ws = self._workspace(B, False, slot)
+        lp = self._params_lp()
+        with torch.cuda.device(cache.device):
+            _lib.check(_lib.lib().sq_vis_forward_ex(ctypes.byref(self.cfg), self.compute_dtype, _lib.ptr(self.flat), _lib.ptr(lp), None,
+                                                    _lib.ptr(cache), _lib.ptr(members), cache.shape[0], None, _lib.ptr(out), B, 0,
+                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(cache.device)))
+        return out
+
+    def apply_head(self, head_in):
+        """linear_head[1] of the reference (tformer_lin.py:91-94,106) on already normalised inputs f32 [R, D] -> f32 [R, G]."""
+        R, D = head_in.shape
+        G = self.cfg.num_outputs
+        lay, dev = self.layout, head_in.device
+        lp = self._params_lp()
+        out = torch.empty(R, G, dtype=torch.float32, device=dev)
+        if lp is not None:
+            a = head_in.to(torch.bfloat16).contiguous()
+            w_ptr = ctypes.c_void_p(lp.data_ptr() + 2 * lay.head_w)
+        else:
+            a = head_in.contiguous()
+            w_ptr = ctypes.c_void_p(self.flat.data_ptr() + 4 * lay.head_w)
+        b_ptr = ctypes.c_void_p(self.flat.data_ptr() + 4 * lay.head_b)
+        with torch.cuda.device(dev):
+            for r0 in range(0, R, 32768):                  # operand extents stay below the 2 GiB buffer-descriptor limit
+                r1 = min(R, r0 + 32768)
+                _lib.check(_lib.lib().sq_linear(self.compute_dtype, _lib.ptr(a[r0:r1]), D, w_ptr, D, b_ptr, None, 0, 0, 0,
+                                                _lib.ptr(out[r0:r1]), _lib.SQ_F32, G, r1 - r0, G, D, None, 0, _lib.stream_ptr(dev)))
+        return out
+
     def _run_backward(self, grad_out, batch, need_x_grad):
         from . import train as _train           # sq_vis_backward binding lives with the training step
         return _train.vis_backward(self, grad_out, batch, need_x_grad)
