@@ -60,6 +60,12 @@ struct BtlArgs {
     const float* b2; const float* b3; const float* b1n;
     int P, W, HW, tiles;
     uint32_t w2_bytes, w3_bytes, w1n_bytes;     // descriptor extents (to the end of the packed weight buffer)
+    // downsample form (first block of the stage): the identity is  xin . wd^T + bd  (src/resnet.py:87-88), computed
+    // here per 128-channel slice from the block's 64-channel input instead of being read as a 256-channel tensor
+    const bf16_t* xin;     // [P, 64]
+    const bf16_t* wd;      // [256, 64]
+    const float* bd;
+    uint32_t wd_bytes;
 };
 
 constexpr int R0_BYTES = 32768;     // t1 halo rows (128 B each)  /  identity -> y chunk [128 px][128 ch] (256-B rows)
@@ -67,7 +73,7 @@ constexpr int R1_BYTES = 16384;     // t2 [128 px][64 ch] (128-B rows); later th
 constexpr int WB_BYTES = 16384;     // one weight chunk
 constexpr int LDS_BYTES = R0_BYTES + R1_BYTES + 2 * WB_BYTES;
 
-template <int CN>
+template <int CN, bool DS>
 __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const R0 = smem;
@@ -93,12 +99,16 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
     const auto rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (int)p.w2_bytes, 0x00020000);
     const auto rsW3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
     const auto rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1n, 0, (int)p.w1n_bytes, 0x00020000);
+    const auto rsWd = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.wd : p.w3), 0, (int)(DS ? p.wd_bytes : p.w3_bytes), 0x00020000);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.xin : p.t1), 0, p.P * 128, 0x00020000);
 
     // ---- weight chunk stream -------------------------------------------------------------------------------
     // chunk ids: 0..4 = 3x3 taps (2i, 2i+1), rows [64 n][256 B];  then per 128-channel slice nc of y:
     //   B_nc = w3 rows nc*128.. [128 n][128 B];  C_nc = w1' columns nc*128.. : CN = 64 one chunk [64 n][256 B],
     //   CN = 128 two chunks [128 n][128 B] (k halves)
-    constexpr int CPS = CN == 64 ? 2 : 3;           // chunks per y slice
+    //   downsample form: one more chunk in front of B_nc, D_nc = wd rows nc*128.. [128 n][128 B]
+    constexpr int NDS = DS ? 1 : 0;
+    constexpr int CPS = (CN == 64 ? 2 : 3) + NDS;   // chunks per y slice
     constexpr int NCHUNK = 5 + 2 * CPS;
     auto issue_chunk = [&](int id, int buf) {
         char* dst = WB + buf * WB_BYTES + wave * 1024;
@@ -111,8 +121,12 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
                 off = (uint32_t)(n * 576 + id * 128 + c * 8) * 2u;
                 glds16(rsW2, dst + u * 4096, off);
             } else {
-                const int s = id - 5, nc = s / CPS, which = s % CPS;
-                if (which == 0) {                    // [128][128 B]: w3 row nc*128 + n
+                const int s = id - 5, nc = s / CPS, which = s % CPS - NDS;
+                if (which < 0) {                     // [128][128 B]: wd row nc*128 + n
+                    const int n = q >> 3, c = (q & 7) ^ ((n >> 1) & 7);
+                    off = (uint32_t)((nc * 128 + n) * 64 + c * 8) * 2u;
+                    glds16(rsWd, dst + u * 4096, off);
+                } else if (which == 0) {             // [128][128 B]: w3 row nc*128 + n
                     const int n = q >> 3, c = (q & 7) ^ ((n >> 1) & 7);
                     off = (uint32_t)((nc * 128 + n) * 64 + c * 8) * 2u;
                     glds16(rsW3, dst + u * 4096, off);
@@ -217,11 +231,58 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
     // ============================ stages B / C per 128-channel slice of y =====================================
 #pragma unroll
     for (int nc = 0; nc < 2; ++nc) {
-        const int idB = 5 + nc * CPS;
+        const int idD = 5 + nc * CPS, idB = idD + NDS;
+        if constexpr (DS) {
+            // ---- D: identity slice = xin . wd[nc*128 ..]^T + bd, rounded to bf16 like the separate launch would ----
+            __syncthreads();                         // chunk D landed; everyone is done with R0 (halo / previous y slice)
+            issue_chunk(idD + 1, (idD + 1) & 1);
+            char* xreg = R0 + wave * 8192;           // this wave's 32 x-rows (128 B each) at the head of its own y rows
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = u * 64 + lane;
+                const int ml = q >> 3, c = (q & 7) ^ ((ml >> 1) & 7);
+                const int pr = p0 + wave * 32 + ml;
+                glds16(rsX, xreg + u * 1024, pr < p.P ? (uint32_t)(pr * 64 + c * 8) * 2u : OOB);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            f32x16 accd[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accd[i][e] = 0.f;
+            {
+                const char* wb = WB + (idD & 1) * WB_BYTES;
+                const char* arow = xreg + l31 * 128;
+                const int sw = (l31 >> 1) & 7;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 x = lds128(arow + (((2 * ks + lh) ^ sw) << 4));
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int n = nt * 32 + l31;
+                        accd[nt] = mma(lds128(wb + n * 128 + (((2 * ks + lh) ^ ((n >> 1) & 7)) << 4)), x, accd[nt]);
+                    }
+                }
+            }
+            {
+                char* row = R0 + m * 256;
+                const int sw = m & 15;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n0 = nt * 32 + 8 * g + 4 * lh;
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bd + nc * 128 + n0);
+                        st_lds64(row + (((nt * 4 + g) ^ sw) << 4) + 8 * lh,
+                                 u32x2{pack_bf16x2(accd[nt][4 * g + 0] + b[0], accd[nt][4 * g + 1] + b[1]),
+                                       pack_bf16x2(accd[nt][4 * g + 2] + b[2], accd[nt][4 * g + 3] + b[3])});
+                    }
+            }
+        }
         // ---- B: y slice = t2 . w3[nc*128 ..]^T -----------------------------------------------------------
-        __syncthreads();                             // chunk B landed; everyone is done with R0 (halo / previous y slice)
+        __syncthreads();                             // chunk B landed; (plain form) everyone is done with R0
         issue_chunk(idB + 1, (idB + 1) & 1);
-        {   // identity slice -> R0, this wave's 32 rows only (so its arrival needs no barrier)
+        if constexpr (!DS) {   // identity slice -> R0, this wave's 32 rows only (so its arrival needs no barrier)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int q = u * 64 + lane;
@@ -283,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
         }
         // ---- C: t1' += y slice . w1'[:, nc*128 ..]^T -------------------------------------------------------
 #pragma unroll
-        for (int hc = 0; hc < CPS - 1; ++hc) {
+        for (int hc = 0; hc < CPS - 1 - NDS; ++hc) {
             const int idC = idB + 1 + hc;
             __syncthreads();                         // chunk C landed; chunk B is consumed
             if (idC + 1 < NCHUNK) issue_chunk(idC + 1, (idC + 1) & 1);
@@ -365,37 +426,48 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
 }  // namespace
 
 // t1 [P, 64], res / y [P, 256], t1n [P, cn] (cn = 64 or 128), all bf16; P = n * H * W pixels of W-wide square maps.
+// Downsample form: res == nullptr, the identity is xin [P, 64] . wd^T + bd.
 // w*_bytes: bytes from each weight pointer to the end of its allocation (descriptor extent; the tail chunk of the
 // 3x3 weights over-reads 128 bytes past row 63, which must stay inside the packed weight buffer).
 int sq_launch_bottleneck_tail_c64(const bf16_t* t1, const bf16_t* res, bf16_t* y, bf16_t* t1n, int cn,
                                   const bf16_t* w2, const bf16_t* w3, const bf16_t* w1n, size_t w2_bytes, size_t w3_bytes, size_t w1n_bytes,
-                                  const float* b2, const float* b3, const float* b1n, int n_img, int H, int W, hipStream_t stream) {
+                                  const float* b2, const float* b3, const float* b1n,
+                                  const bf16_t* xin, const bf16_t* wd, size_t wd_bytes, const float* bd,
+                                  int n_img, int H, int W, hipStream_t stream) {
     SQ_REQUIRE(cn == 64 || cn == 128, "bottleneck tail: next width %d (64 or 128)", cn);
     SQ_REQUIRE(H == W && W >= 3 && (128 + 2 * W + 2) * 128 <= R0_BYTES, "bottleneck tail: map %d x %d does not fit the halo buffer", H, W);
     const long long P = (long long)n_img * H * W;
     SQ_REQUIRE(P > 0 && P * 512 < (1ll << 31), "bottleneck tail: %lld pixels exceed the 2 GiB descriptor limit", P);
     SQ_REQUIRE(w2_bytes >= 64 * 576 * 2 + 128 && w3_bytes >= 256 * 64 * 2 && w1n_bytes >= (size_t)cn * 256 * 2, "bottleneck tail: weight extents");
+    const bool ds = res == nullptr;
+    SQ_REQUIRE(!ds || (xin && wd && bd && wd_bytes >= 256 * 64 * 2), "bottleneck tail: neither an identity tensor nor a downsample branch");
     BtlArgs a;
     a.t1 = t1; a.res = res; a.y = y; a.t1n = t1n; a.w2 = w2; a.w3 = w3; a.w1n = w1n; a.b2 = b2; a.b3 = b3; a.b1n = b1n;
+    a.xin = xin; a.wd = wd; a.bd = bd;
     a.P = (int)P; a.W = W; a.HW = H * W; a.tiles = (int)((P + 127) / 128);
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
-    a.w2_bytes = clamp(w2_bytes); a.w3_bytes = clamp(w3_bytes); a.w1n_bytes = clamp(w1n_bytes);
+    a.w2_bytes = clamp(w2_bytes); a.w3_bytes = clamp(w3_bytes); a.w1n_bytes = clamp(w1n_bytes); a.wd_bytes = clamp(wd_bytes);
     static bool attr = false;
     if (!attr) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr = true;
     }
     int prof = -1;
     if (sq_prof_on()) {
         char name[96];
-        snprintf(name, sizeof(name), "btl_tail_c64_cn%d_P%lld", cn, P);
-        const double flops = 2.0 * P * (576.0 * 64 + 64.0 * 256 + 256.0 * cn);
-        const double bytes = (double)P * 2.0 * (64 + 256 + 256 + cn) + 2.0 * (64 * 576 + 256 * 64 + cn * 256);
+        snprintf(name, sizeof(name), "btl_tail_c64_cn%d%s_P%lld", cn, ds ? "_ds" : "", P);
+        const double flops = 2.0 * P * (576.0 * 64 + 64.0 * 256 + 256.0 * cn + (ds ? 64.0 * 256 : 0.0));
+        const double bytes = (double)P * 2.0 * (64 + (ds ? 64 : 256) + 256 + cn) + 2.0 * (64 * 576 + 256 * 64 * (ds ? 2 : 1) + cn * 256);
         prof = sq_prof_begin(name, flops, bytes, stream);
     }
-    if (cn == 64) hipLaunchKernelGGL(btl_tail_kernel<64>, dim3(a.tiles), dim3(256), LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(btl_tail_kernel<128>, dim3(a.tiles), dim3(256), LDS_BYTES, stream, a);
+    const dim3 grid(a.tiles), block(256);
+    if (cn == 64 && !ds) hipLaunchKernelGGL((btl_tail_kernel<64, false>), grid, block, LDS_BYTES, stream, a);
+    else if (cn == 128 && !ds) hipLaunchKernelGGL((btl_tail_kernel<128, false>), grid, block, LDS_BYTES, stream, a);
+    else if (cn == 64) hipLaunchKernelGGL((btl_tail_kernel<64, true>), grid, block, LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((btl_tail_kernel<128, true>), grid, block, LDS_BYTES, stream, a);
     SQ_LAUNCH_CHECK();
     if (prof >= 0) sq_prof_end(prof, stream);
     return SQ_OK;

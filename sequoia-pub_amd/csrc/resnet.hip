@@ -17,7 +17,9 @@
 
 int sq_launch_bottleneck_tail_c64(const bf16_t* t1, const bf16_t* res, bf16_t* y, bf16_t* t1n, int cn,
                                   const bf16_t* w2, const bf16_t* w3, const bf16_t* w1n, size_t w2_bytes, size_t w3_bytes, size_t w1n_bytes,
-                                  const float* b2, const float* b3, const float* b1n, int n_img, int H, int W, hipStream_t stream);
+                                  const float* b2, const float* b3, const float* b1n,
+                                  const bf16_t* xin, const bf16_t* wd, size_t wd_bytes, const float* bd,
+                                  int n_img, int H, int W, hipStream_t stream);
 int sq_launch_conv1_pool_bf16(const uint8_t* u8, const float* f32_nchw, const bf16_t* w152, const float* bias, bf16_t* out,
                               int n, int S, hipStream_t stream);
 
@@ -293,17 +295,16 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
             if (t1i < 0) RUN(conv(c1, x, H, t1, H, nullptr, SQ_ACT_RELU));
             const int cnext = ci + (has_ds ? 4 : 3);
             if (fuse56 && li == 0) {
-                void* ds = b.act[free_[0]]; void* y = b.act[free_[1]]; void* t1n = b.act[free_[2]];
-                const void* identity = x;
-                if (has_ds) {
-                    RUN(conv(lay.conv[ci + 3], x, H, ds, OH, nullptr, SQ_ACT_NONE));
-                    identity = ds;
-                }
+                void* y = b.act[free_[1]]; void* t1n = b.act[free_[2]];
                 const sq_conv_desc& n1 = lay.conv[cnext];
+                const sq_conv_desc& dsd = lay.conv[ci + 3];           // only read when has_ds
                 auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
-                RUN(sq_launch_bottleneck_tail_c64((const bf16_t*)t1, (const bf16_t*)identity, (bf16_t*)y, (bf16_t*)t1n, n1.cout,
+                // first block: the downsample branch (64 -> 256, stride 1 here) is computed inside the launch from x
+                RUN(sq_launch_bottleneck_tail_c64((const bf16_t*)t1, has_ds ? nullptr : (const bf16_t*)x, (bf16_t*)y, (bf16_t*)t1n, n1.cout,
                                                   (const bf16_t*)W(c2), (const bf16_t*)W(c3), (const bf16_t*)W(n1), rest(c2), rest(c3), rest(n1),
-                                                  bias + c2.b_off, bias + c3.b_off, bias + n1.b_off, n, H, H, st));
+                                                  bias + c2.b_off, bias + c3.b_off, bias + n1.b_off,
+                                                  has_ds ? (const bf16_t*)x : nullptr, has_ds ? (const bf16_t*)W(dsd) : nullptr,
+                                                  has_ds ? rest(dsd) : 0, has_ds ? bias + dsd.b_off : nullptr, n, H, H, st));
                 xi = free_[1];
                 t1i = free_[2];
                 ci = cnext;
