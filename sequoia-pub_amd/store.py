@@ -3,9 +3,11 @@
 The reference keeps per-slide tensors in HDF5 files ``<feature_path>/<project>/<WSI>/<WSI>.h5`` with datasets
 ``resnet_features | uni_features [n, D]`` and ``cluster_features [100, D]`` (compute_features_hdf5.py:134-135,
 kmean_features.py:108), and patches in ``<patch_path>/<slide>/<slide>.hdf5`` with one uint8 ``[S, S, 3]``
-dataset per tile named ``"{x}_{y}"`` (patch_gen_hdf5.py:119-120).  ``h5py`` is used when importable (real
-SEQUOIA stores then work unchanged); otherwise the same dataset names live as ``.npy`` files inside a
-directory with the HDF5 file's path + ``.d`` -- same keys, same dtypes, same shapes."""
+dataset per tile named ``"{x}_{y}"`` (patch_gen_hdf5.py:119-120).  Backends, in order: ``h5py`` when importable;
+``h5lite`` -- the HDF5 C library through ctypes (this image ships libhdf5 but not h5py) -- so the files are REAL HDF5
+either way and real SEQUOIA stores work unchanged; only when neither exists do the same dataset names live as
+``.npy`` files inside a directory with the HDF5 file's path + ``.d`` (same keys, dtypes, shapes).
+``SEQUOIA_STORE=npy`` forces that mirror (tests)."""
 import os
 
 import numpy as np
@@ -16,6 +18,17 @@ try:
 except Exception:
     h5py = None
     HAVE_H5PY = False
+
+from . import h5lite
+
+
+def backend():
+    """'h5py', 'h5lite' (libhdf5 through ctypes) or 'npy' (directory mirror)."""
+    if os.environ.get("SEQUOIA_STORE") == "npy":
+        return "npy"
+    if HAVE_H5PY:
+        return "h5py"
+    return "h5lite" if h5lite.available() else "npy"
 
 
 class _NpyDirFile:
@@ -62,8 +75,9 @@ class _NpyDirFile:
 def File(path, mode="r"):
     """h5py.File-compatible handle (subset: keys / [] / create_dataset / close / context manager).
     Modes: "r", "w", "r+" (append to an existing store)."""
-    if HAVE_H5PY and ((mode == "w" and not os.path.isdir(path + ".d")) or os.path.isfile(path)):
-        return h5py.File(path, mode)
+    be = backend()
+    if be != "npy" and ((mode == "w" and not os.path.isdir(path + ".d")) or os.path.isfile(path)):
+        return h5py.File(path, mode) if be == "h5py" else h5lite.File(path, mode)
     return _NpyDirFile(path, "a" if mode == "r+" else mode)
 
 
