@@ -243,14 +243,23 @@ def workload_pipeline(args, rank, world, device):
     from sequoia_pub_amd.vis import ViS
     nslides, npatch = args.slides, args.patches
     torch.manual_seed(99)
-    rn = resnet50(pretrained=False, compute_dtype=args.dtype).to(device).eval()
-    for m in rn.modules():                     # non-trivial BN statistics so folding is exercised
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.running_mean.normal_(0, 0.1)
-            m.running_var.uniform_(0.5, 1.5)
-    cfg = dict(VIS_CFG, input_dim=2048)
+    uni = args.embedder == "uni"
+    if uni:                                    # the UNI ViT-L/16 extractor (compute_features_hdf5.py --feat_type uni): 1024-d features
+        from sequoia_pub_amd.uni import create_model
+        rn = create_model(compute_dtype=args.dtype).to(device).eval()
+        with torch.no_grad():                  # LayerScale at its init value (1e-5) would switch the blocks off numerically
+            for k, (off, shape) in rn._tmap.items():
+                if k.endswith("gamma"):
+                    rn.flat[off:off + shape[0]] = 0.3
+    else:
+        rn = resnet50(pretrained=False, compute_dtype=args.dtype).to(device).eval()
+        for m in rn.modules():                 # non-trivial BN statistics so folding is exercised
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    cfg = dict(VIS_CFG, input_dim=1024 if uni else 2048)
     vis = ViS(**cfg, num_clusters=100, device=str(device), compute_dtype=args.dtype).to(device).eval()
-    pipe = SlidePipeline(rn, vis, sub_batch=args.sub_batch)
+    pipe = SlidePipeline(rn, vis, sub_batch=min(args.sub_batch, 256) if uni else args.sub_batch)
     # streaming form (default): the last slide's k-Means + ViS forward of a step run under the next step's first ResNet;
     # whatever is still in flight is flushed inside the timed region.  --no-stream: every step completes on its own.
     run = pipe if args.no_stream else pipe.submit
@@ -284,21 +293,23 @@ def workload_pipeline(args, rank, world, device):
         compute_features_hdf5.py:116-123 (one forward + one result copy per patch) on a sample of patches, the same
         sample batched (so the speed-up is not inflated by the reference's loop structure), then ONE oracle
         k-Means(100) + cluster means + ViS forward; per-slide time = 1000 x per-patch time + the rest."""
-        from oracle import kmeans_oracle, resnet_oracle, vis_oracle
+        from oracle import kmeans_oracle, resnet_oracle, uni_oracle, vis_oracle
         sd_r = {k: v.cpu() for k, v in rn.state_dict().items()}
         sd_v = {k: v.cpu() for k, v in vis.state_dict().items()}
         ncpu = os.cpu_count() or 1
         torch.set_num_threads(min(ncpu, 64))
-        n_lit, n_bat = 96, 128
+        n_lit, n_bat = (12, 16) if uni else (96, 128)
+        embed = (lambda p, batch: uni_oracle.embed_patches(sd_r, p, heads=16, batch=batch)) if uni else \
+                (lambda p, batch: resnet_oracle.embed_patches(sd_r, p, batch=batch))
         sample = host[0][:n_bat].cpu() if isinstance(host[0], torch.Tensor) else host[0][:n_bat]
-        resnet_oracle.embed_patches(sd_r, sample[:2], batch=1)                      # warm the thread pool
+        embed(sample[:2], 1)                                                        # warm the thread pool
         t0 = time.perf_counter()
-        out = [resnet_oracle.embed_patches(sd_r, sample[i:i + 1], batch=1)[0].numpy() for i in range(n_lit)]
+        out = [embed(sample[i:i + 1], 1)[0].numpy() for i in range(n_lit)]
         t_lit = (time.perf_counter() - t0) / n_lit
         t0 = time.perf_counter()
-        resnet_oracle.embed_patches(sd_r, sample, batch=n_bat)
+        embed(sample, n_bat)
         t_bat = (time.perf_counter() - t0) / n_bat
-        feats = synth.features_gmm(5, npatch, 2048)
+        feats = synth.features_gmm(5, npatch, 1024 if uni else 2048)
         t0 = time.perf_counter()
         r = kmeans_oracle.kmeans_fit(feats)
         cf = kmeans_oracle.cluster_means(feats, r["labels"])
@@ -310,12 +321,13 @@ def workload_pipeline(args, rank, world, device):
                 "batched_value": round(bat, 5),
                 "sample": f"config 1 restated (oracle/, torch-CPU fp32): literal batch-1 loop on {n_lit} patches "
                           f"({t_lit * 1e3:.1f} ms/patch) and the same arithmetic in one batch of {n_bat} ({t_bat * 1e3:.1f} ms/patch), "
-                          f"each extrapolated to {npatch} patches, + one oracle k-Means(100) + cluster means + ViS(D=2048) forward "
+                          f"each extrapolated to {npatch} patches, + one oracle k-Means(100) + cluster means + ViS forward "
                           f"({t_rest:.2f} s); value = literal, batched_value = batched"}
 
     return dict(step=step, flush=None if args.no_stream else pipe.flush, slides_per_step=nslides, cpu_baseline=cpu_baseline,
-                config={"workload": "pipeline: 1000 x 224x224 uint8 patches/slide -> ResNet-50 embed -> k-Means(100) -> "
-                                    "ViS(D=2048, depth 6, 16 heads, G=20820) forward (BASELINE config 3), " +
+                config={"workload": "pipeline: 1000 x 224x224 uint8 patches/slide -> " +
+                                    ("UNI ViT-L/16 embed -> k-Means(100) -> ViS(D=1024, depth 6, 16 heads, G=20820) forward (the metric's UNI-dim variant), "
+                                     if uni else "ResNet-50 embed -> k-Means(100) -> ViS(D=2048, depth 6, 16 heads, G=20820) forward (BASELINE config 3), ") +
                                     ("patches uploaded from pinned host memory every step" if args.from_host else "patches resident in HBM"),
                         "slides_per_step_per_gpu": nslides, "patches_per_slide": npatch,
                         "parallelism": f"slide-sharded x{world}"})
@@ -425,6 +437,7 @@ WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train, "pipe
 
 METRIC = "slides/sec (1000-patch WSI, UNI-dim, 20k-gene head)"
 RESNET_FLOP_PER_PATCH = 8.174e9          # 4.087 GMAC per 224 x 224 patch
+UNI_FLOP_PER_PATCH = 122.6e9             # ViT-L/16 at 197 tokens: 61.3 GMAC (24 blocks x (4 D^2 + 2 D mlp) per token + attention)
 VIS_FWD_FLOP = {1024: 5.17e9, 2048: 15.4e9}   # per slide, algorithmic (s(mean x) shortcut): 6 layers of f / projection / 2 FF products + head
 
 
@@ -471,7 +484,7 @@ def measure(name, args, rank, world, device, want_roofline=True, want_cpu=True):
         if wl.get("flush"):
             wl["flush"]()
         if roof is not None and name == "pipeline":
-            flop = args.patches * RESNET_FLOP_PER_PATCH + VIS_FWD_FLOP[2048]
+            flop = args.patches * (UNI_FLOP_PER_PATCH if args.embedder == "uni" else RESNET_FLOP_PER_PATCH) + VIS_FWD_FLOP[1024 if args.embedder == "uni" else 2048]
             roof["end_to_end"] = {"algorithmic_tflop_per_slide": round(flop / 1e12, 3),
                                   "achieved_tflops": round(flop * value / world / 1e12, 1), "peak_tflops": PEAK[args.dtype],
                                   "frac_of_mfma_peak": round(flop * value / world / 1e12 / PEAK[args.dtype], 4)}
@@ -500,6 +513,7 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=500, help="pipeline workload: patches per ResNet launch group")
     ap.add_argument("--grid", type=int, nargs=2, default=[250, 200], help="spatial workload: tile grid")
     ap.add_argument("--batch-windows", type=int, default=1024, help="spatial workload: windows per ViS forward")
+    ap.add_argument("--embedder", default="resnet", choices=["resnet", "uni"], help="pipeline workload: patch embedder")
     ap.add_argument("--no-stream", action="store_true", help="pipeline workload: finish every step's slides before the next step starts")
     ap.add_argument("--from-host", action="store_true", help="pipeline workload: upload the patches from pinned host memory every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -545,7 +559,8 @@ def main():
         sec = {}
         for key, extra in (("pipeline_from_pinned_host", ["--workload", "pipeline", "--from-host"]),
                            ("vis_train_bf16", ["--workload", "vis_train"]),
-                           ("pipeline_fp32_parity_mode", ["--workload", "pipeline", "--dtype", "fp32", "--slides", "2", "--sub-batch", "250"])):
+                           ("pipeline_fp32_parity_mode", ["--workload", "pipeline", "--dtype", "fp32", "--slides", "2", "--sub-batch", "250"]),
+                           ("pipeline_uni_vit_l16_embedder", ["--workload", "pipeline", "--embedder", "uni", "--slides", "2"])):
             cmd = [sys.executable, os.path.abspath(__file__), "--no-secondary", "--no-cpu-baseline", "--warmup", str(args.warmup)] + extra
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)

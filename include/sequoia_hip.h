@@ -255,6 +255,35 @@ int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const f
 int sq_linear_weight_grad(int dtype, const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, float* dbias,
                           int n_out, int n_in, int n_tokens, void* workspace, size_t workspace_bytes, sq_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * UNI patch embedder: timm ``vit_large_patch16_224`` with ``init_values=1e-5, num_classes=0`` as
+ * /root/reference/pre_processing/compute_features_hdf5.py:62-68 and spatial_vis/visualize.py:220-232 build it
+ * (``feat_model(image)`` at :127-129 returns the normalised class token, [1, 1024]).  timm is not vendored in the
+ * reference and absent here: the entry points follow timm's published VisionTransformer algorithm.
+ *
+ * sq_uni_layout: element offsets into ONE flat fp32 buffer; every timm tensor (patch_embed.proj, cls_token, pos_embed,
+ * blocks.{i}.{norm1,attn.qkv,attn.proj,ls1,norm2,mlp.fc1,mlp.fc2,ls2}, norm) is a contiguous slice.
+ * sq_uni_forward: params = that buffer (biases / LayerNorm / embeddings are read from it); params_exec = the same layout
+ * in the compute dtype with the LayerScale gains folded into attn.proj / mlp.fc2 WEIGHTS; bias_exec = fp32 buffer of
+ * the same layout whose attn.proj / mlp.fc2 BIASES carry the gains.  Give EITHER patches_u8 (uint8 NHWC [n, S, S, 3]:
+ * ToTensor + Normalize of compute_features_hdf5.py:53-56 are fused in; S must equal img_size) OR patches_f32_nchw
+ * (normalised, the reference's tensor).  out: f32 [n, dim].
+ * ---------------------------------------------------------------------------------------------------------- */
+#define SQ_UNI_MAX_DEPTH 32
+typedef struct sq_uni_config { int32_t dim, depth, heads, mlp_dim, img_size; } sq_uni_config;
+typedef struct sq_uni_layer_offsets {
+    int64_t ln1_g, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ls1, ln2_g, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b, ls2;
+} sq_uni_layer_offsets;
+typedef struct sq_uni_layout {
+    int64_t patch_w, patch_b, cls, pos, norm_g, norm_b, total;
+    sq_uni_layer_offsets layer[SQ_UNI_MAX_DEPTH];
+} sq_uni_layout;
+int sq_uni_layout_init(const sq_uni_config* cfg, sq_uni_layout* out);
+size_t sq_uni_workspace_bytes(const sq_uni_config* cfg, int dtype, int n_patches);
+int sq_uni_forward(const sq_uni_config* cfg, int dtype, const float* params, const void* params_exec, const float* bias_exec,
+                   const uint8_t* patches_u8, const float* patches_f32_nchw, int n_patches, float* out, void* workspace,
+                   size_t workspace_bytes, sq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
