@@ -20,6 +20,9 @@ int sq_launch_bottleneck_tail_c64(const bf16_t* t1, const bf16_t* res, bf16_t* y
                                   const float* b2, const float* b3, const float* b1n,
                                   const bf16_t* xin, const bf16_t* wd, size_t wd_bytes, const float* bd,
                                   int n_img, int H, int W, hipStream_t stream);
+int sq_launch_bottleneck_chain_c128(const bf16_t* t2, const bf16_t* res, bf16_t* y, bf16_t* t1n, int cn, const bf16_t* w3,
+                                    const bf16_t* w1n, size_t w3_bytes, size_t w1n_bytes, const float* b3, const float* b1n,
+                                    long long P, hipStream_t stream);
 int sq_launch_conv1_pool_bf16(const uint8_t* u8, const float* f32_nchw, const bf16_t* w152, const float* bias, bf16_t* out,
                               int n, int S, hipStream_t stream);
 
@@ -281,6 +284,7 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
     // bf16, 56 x 56 stage (layer 1): the 3x3, the expand 1x1 (+ identity, ReLU) and the NEXT block's reduce 1x1 are one
     // launch (bottleneck.hip) -- that block's conv1 output then already sits in act[t1i] when its turn comes.
     const bool fuse56 = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && (128 + 2 * H + 2) * 128 <= 32768;
+    const bool fuse_chain = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && !sq_env_flag("SQ_RESNET_NO_CHAIN");
     int xi = 1, ci = 1, t1i = -1;
     const int blocks[4] = {3, 4, 6, 3};
     for (int li = 0; li < 4; ++li)
@@ -288,7 +292,8 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
             int free_[4], nf = 0;
             for (int i = 0; i < 5; ++i) if (i != xi && i != t1i) free_[nf++] = i;
             void* x = b.act[xi];
-            void* t1 = t1i >= 0 ? b.act[t1i] : b.act[free_[--nf]];
+            const int t1_idx = t1i >= 0 ? t1i : free_[--nf];
+            void* t1 = b.act[t1_idx];
             const sq_conv_desc& c1 = lay.conv[ci]; const sq_conv_desc& c2 = lay.conv[ci + 1]; const sq_conv_desc& c3 = lay.conv[ci + 2];
             const bool has_ds = bk == 0;
             const int OH = H / c2.stride;
@@ -316,6 +321,21 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
             if (has_ds) {
                 RUN(conv(lay.conv[ci + 3], x, H, ds, OH, nullptr, SQ_ACT_NONE));
                 identity = ds;
+            }
+            // 128-plane stage (28 x 28): expand 1x1 + identity + ReLU and the NEXT block's reduce 1x1 in one launch
+            // (chain.hip); its output lands in the buffer conv1's output occupied (dead once conv2 has read it)
+            if (fuse_chain && c3.cin == 128 && c3.cout == 512 && cnext < SQ_RESNET50_CONVS && lay.conv[cnext].k == 1 &&
+                lay.conv[cnext].cin == 512 && (lay.conv[cnext].cout == 128 || lay.conv[cnext].cout == 256)) {
+                const sq_conv_desc& n1 = lay.conv[cnext];
+                auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
+                RUN(sq_launch_bottleneck_chain_c128((const bf16_t*)t2, (const bf16_t*)identity, (bf16_t*)y, (bf16_t*)t1, n1.cout,
+                                                    (const bf16_t*)W(c3), (const bf16_t*)W(n1), rest(c3), rest(n1), bias + c3.b_off,
+                                                    bias + n1.b_off, (long long)n * OH * OH, st));
+                ci = cnext;
+                xi = free_[2];
+                t1i = t1_idx;
+                H = OH;
+                continue;
             }
             RUN(conv(c3, t2, OH, y, OH, identity, SQ_ACT_RELU));       // relu(bn3(conv3) + identity)
             ci = cnext;
