@@ -24,6 +24,8 @@
 
 bool sq_gemm256_eligible(const GemmArgs& a, int dtype);
 int sq_launch_gemm256(const GemmArgs& a, hipStream_t stream);
+bool sq_conv_halo_eligible(const GemmArgs& a, int dtype);
+int sq_launch_conv_halo(const GemmArgs& a, hipStream_t stream);
 bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype);
 int sq_launch_gemm_ring(const GemmArgs& a, hipStream_t stream);
 
@@ -550,6 +552,8 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
     if (g_force_split > 0 && a.splitk_ws && a.N % 8 == 0) a.splitk = g_force_split;
     if constexpr (sizeof(T) == 2) {
         // long-K products with enough 256 x 128 tiles: three-stage ring kernel (gemm_ring.hip); SQ_GEMM_RING=0 turns it off
+        // 3x3 / stride-1 convolutions with enough 256 x 128 tiles: input tile resident in LDS (conv_halo.hip)
+        if (g_force_tile == 0 && a.splitk == 1 && sq_conv_halo_eligible(a, SQ_BF16)) return sq_launch_conv_halo(a, stream);
         if (g_use_ring < 0) { const char* e = getenv("SQ_GEMM_RING"); g_use_ring = (e && e[0] == '0') ? 0 : 1; }
         if (a.splitk == 1 && (g_force_tile == 33 || (g_force_tile == 0 && g_use_ring && sq_gemm_ring_eligible(a, SQ_BF16))) && a.N % 8 == 0)
             return sq_launch_gemm_ring(a, stream);

@@ -90,3 +90,23 @@ def test_fused_bottleneck_tail_is_bit_identical(monkeypatch):
         assert torch.isfinite(fused).all()
         assert torch.equal(fused, plain), (npatch, float((fused - plain).abs().max()))
     monkeypatch.delenv("SQ_RESNET_NO_FUSE", raising=False)
+
+
+def test_halo_staged_3x3_matches_implicit_gemm(monkeypatch):
+    """conv_halo.hip (input tile resident in LDS, channel-block-major K order) against the tap-major implicit-GEMM
+    kernels on the same network: same features up to the bf16 re-rounding the different fp32 summation order causes,
+    and both within the bf16 tolerance of the fp32 mode."""
+    _lib.require_gpu()
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for halo in ("1", "0"):                       # the switch is read once per process
+        env = dict(os.environ, SQ_CONV_HALO=halo, SQ_CONV_HALO_MIN_TILES="1")
+        p = os.path.join("/tmp", f"sq_halo_{halo}_{os.getpid()}.pt")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "halo_check.py"), p], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        outs.append(torch.load(p))
+        os.remove(p)
+    a, b = outs
+    assert torch.isfinite(a).all() and not torch.equal(a, b)            # a different kernel really ran
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-2
