@@ -20,6 +20,9 @@ int sq_launch_bottleneck_tail_c64(const bf16_t* t1, const bf16_t* res, bf16_t* y
                                   const float* b2, const float* b3, const float* b1n,
                                   const bf16_t* xin, const bf16_t* wd, size_t wd_bytes, const float* bd,
                                   int n_img, int H, int W, hipStream_t stream);
+int sq_launch_bottleneck_chain_c256(const bf16_t* t2, const bf16_t* res, bf16_t* y, bf16_t* t1n, const bf16_t* w3,
+                                    const bf16_t* w1n, size_t w3_bytes, size_t w1n_bytes, const float* b3, const float* b1n,
+                                    long long P, hipStream_t stream);
 int sq_launch_bottleneck_chain_c128(const bf16_t* t2, const bf16_t* res, bf16_t* y, bf16_t* t1n, int cn, const bf16_t* w3,
                                     const bf16_t* w1n, size_t w3_bytes, size_t w1n_bytes, const float* b3, const float* b1n,
                                     long long P, hipStream_t stream);
@@ -285,6 +288,7 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
     // launch (bottleneck.hip) -- that block's conv1 output then already sits in act[t1i] when its turn comes.
     const bool fuse56 = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && (128 + 2 * H + 2) * 128 <= 32768;
     const bool fuse_chain = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && !sq_env_flag("SQ_RESNET_NO_CHAIN");
+    const bool fuse_chain256 = fuse_chain && !sq_env_flag("SQ_RESNET_NO_CHAIN256");
     int xi = 1, ci = 1, t1i = -1;
     const int blocks[4] = {3, 4, 6, 3};
     for (int li = 0; li < 4; ++li)
@@ -329,6 +333,20 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                 const sq_conv_desc& n1 = lay.conv[cnext];
                 auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
                 RUN(sq_launch_bottleneck_chain_c128((const bf16_t*)t2, (const bf16_t*)identity, (bf16_t*)y, (bf16_t*)t1, n1.cout,
+                                                    (const bf16_t*)W(c3), (const bf16_t*)W(n1), rest(c3), rest(n1), bias + c3.b_off,
+                                                    bias + n1.b_off, (long long)n * OH * OH, st));
+                ci = cnext;
+                xi = free_[2];
+                t1i = t1_idx;
+                H = OH;
+                continue;
+            }
+            // 256-plane stage (14 x 14): the same chain with the t2 rows held in registers (chain256.hip)
+            if (fuse_chain256 && c3.cin == 256 && c3.cout == 1024 && cnext < SQ_RESNET50_CONVS && lay.conv[cnext].k == 1 &&
+                lay.conv[cnext].cin == 1024 && lay.conv[cnext].cout == 256) {
+                const sq_conv_desc& n1 = lay.conv[cnext];
+                auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
+                RUN(sq_launch_bottleneck_chain_c256((const bf16_t*)t2, (const bf16_t*)identity, (bf16_t*)y, (bf16_t*)t1,
                                                     (const bf16_t*)W(c3), (const bf16_t*)W(n1), rest(c3), rest(n1), bias + c3.b_off,
                                                     bias + n1.b_off, (long long)n * OH * OH, st));
                 ci = cnext;

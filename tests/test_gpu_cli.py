@@ -42,12 +42,15 @@ def test_pipeline_clis(tmp_path):
                            "--feature_path", feat, "--max_patch_number", "120", "--weights", wpath])
     f0 = store.File(os.path.join(feat, "TCGA-BRCA", "TCGA-AA-0000", "TCGA-AA-0000.h5"), "r")
     assert np.asarray(f0["resnet_features"][:]).shape == (120, 2048)            # random.sample to max_patch_number
+    f0.close()
     f1 = store.File(os.path.join(feat, "TCGA-BRCA", "TCGA-AA-0001", "TCGA-AA-0001.h5"), "r")
     feats1 = np.asarray(f1["resnet_features"][:])
     assert feats1.shape == (104, 2048) and os.path.exists(os.path.join(feat, "TCGA-BRCA", "TCGA-AA-0001", "complete_tile.txt"))
+    f1.close()                                     # HDF5 refuses "r+" while a read handle is open in the same process
     kmean_features.main(["--ref_file", ref, "--feature_path", feat, "--num_clusters", "100"])
     f1 = store.File(os.path.join(feat, "TCGA-BRCA", "TCGA-AA-0001", "TCGA-AA-0001.h5"), "r")
     cf = np.asarray(f1["cluster_features"][:])
+    f1.close()
     o = kmeans_oracle.kmeans_fit(feats1)
     assert np.array_equal(cf, kmeans_oracle.cluster_means(feats1, o["labels"]))   # same labels, same fp32 means
     kmean_features.main(["--ref_file", ref, "--feature_path", feat])               # resume guard: nothing re-done
