@@ -74,7 +74,7 @@ constexpr int WB_BYTES = 16384;     // one weight chunk
 constexpr int LDS_BYTES = R0_BYTES + R1_BYTES + 2 * WB_BYTES;
 
 template <int CN, bool DS>
-__global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void btl_tail_kernel(const BtlArgs p) {   // LDS allows two blocks per CU: do not trade registers for a third
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const R0 = smem;
     char* const R1 = smem + R0_BYTES;
@@ -101,6 +101,12 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
     const auto rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1n, 0, (int)p.w1n_bytes, 0x00020000);
     const auto rsWd = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.wd : p.w3), 0, (int)(DS ? p.wd_bytes : p.w3_bytes), 0x00020000);
     const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.xin : p.t1), 0, p.P * 128, 0x00020000);
+    // stores go through descriptors as well: rows past P are dropped by the range check, no branch per piece (-4...5 %
+    // for three of the four instantiations; hipcc schedules the branch-free <64, false> with 168 registers and no
+    // fragment read-ahead, +14 %, so that one keeps the guarded stores)
+    constexpr bool BRANCHY = CN == 64 && !DS;
+    const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.P * 512, 0x00020000);
+    const auto rsT1n = __builtin_amdgcn_make_buffer_rsrc((void*)p.t1n, 0, p.P * CN * 2, 0x00020000);
 
     // ---- weight chunk stream -------------------------------------------------------------------------------
     // chunk ids: 0..4 = 3x3 taps (2i, 2i+1), rows [64 n][256 B];  then per 128-channel slice nc of y:
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
             const int row = wave * 32 + (q >> 4), c = (q & 15) ^ (row & 15);
             const int pr = p0 + row;
             const u32x4 v = lds128(R0 + (wave * 32 + u * 4) * 256 + lane * 16);
-            if (pr < p.P) *reinterpret_cast<u32x4*>(p.y + (size_t)pr * 256 + nc * 128 + c * 8) = v;
+            if constexpr (BRANCHY) { if (pr < p.P) *reinterpret_cast<u32x4*>(p.y + (size_t)pr * 256 + nc * 128 + c * 8) = v; }
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rsY, (uint32_t)(pr * 256 + nc * 128 + c * 8) * 2u, 0, 0);
         }
         // ---- C: t1' += y slice . w1'[:, nc*128 ..]^T -------------------------------------------------------
 #pragma unroll
@@ -396,7 +403,8 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
             const int r = wave * 32 + (q >> 3), c = (q & 7) ^ ((r >> 1) & 7);
             const int pr = p0 + r;
             const u32x4 v = lds128(R1 + (wave * 32 + u * 8) * 128 + lane * 16);
-            if (pr < p.P) *reinterpret_cast<u32x4*>(p.t1n + (size_t)pr * 64 + c * 8) = v;
+            if constexpr (BRANCHY) { if (pr < p.P) *reinterpret_cast<u32x4*>(p.t1n + (size_t)pr * 64 + c * 8) = v; }
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rsT1n, (uint32_t)(pr * 64 + c * 8) * 2u, 0, 0);
         }
     } else {
         char* row = R0 + m * 256;                    // the y slice is dead (this wave's rows)
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void btl_tail_kernel(const BtlArgs p) {
             const int r = wave * 32 + (q >> 4), c = (q & 15) ^ (r & 15);
             const int pr = p0 + r;
             const u32x4 v = lds128(R0 + (wave * 32 + u * 4) * 256 + lane * 16);
-            if (pr < p.P) *reinterpret_cast<u32x4*>(p.t1n + (size_t)pr * 128 + c * 8) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsT1n, (uint32_t)(pr * 128 + c * 8) * 2u, 0, 0);
         }
     }
 }

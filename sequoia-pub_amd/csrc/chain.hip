@@ -14,6 +14,7 @@
 #include "gemm.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -45,13 +46,16 @@ struct ChainArgs {
 };
 
 constexpr int C = 128, C4 = 512;
-constexpr int A1_BYTES = 128 * 256;          // t2 tile, 256-byte rows (chunk ^= row & 15)
-constexpr int XY_BYTES = 128 * 128;          // identity -> y slice of 64 channels, 128-byte rows (chunk ^= (row >> 1) & 7)
 constexpr int WB_BYTES = 16384;
-constexpr int LDS_BYTES = A1_BYTES + XY_BYTES + 2 * WB_BYTES;
+constexpr int lds_bytes(int nw) { return nw * 32 * 256 + nw * 32 * 128 + 2 * WB_BYTES; }
 
-template <int CN>
-__global__ __launch_bounds__(256, 2) void btl_chain_kernel(const ChainArgs p) {
+// NW waves = 32 NW pixels per tile.  NW = 4: 80 KiB, two blocks per CU; NW = 8: 128 KiB, one block per CU -- the same
+// eight waves per CU, but every tile streams all the weights, so the larger tile halves the bytes re-loaded from L2.
+template <int CN, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void btl_chain_kernel(const ChainArgs p) {
+    constexpr int TP = 32 * NW;
+    constexpr int A1_BYTES = TP * 256;           // t2 tile, 256-byte rows (chunk ^= row & 15)
+    constexpr int XY_BYTES = TP * 128;           // identity -> y slice of 64 channels, 128-byte rows (chunk ^= (row >> 1) & 7)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const A1 = smem;
     char* const XY = smem + A1_BYTES;
@@ -64,11 +68,14 @@ __global__ __launch_bounds__(256, 2) void btl_chain_kernel(const ChainArgs p) {
         const int b = blockIdx.x, q = p.tiles >> 3, r = p.tiles & 7, xcd = b & 7, idx = b >> 3;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int p0 = t * 128;
+    const int p0 = t * TP;
     const auto rsT2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.t2, 0, p.P * C * 2, 0x00020000);
     const auto rsRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.P * C4 * 2, 0x00020000);
     const auto rsW3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
     const auto rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1n, 0, (int)p.w1n_bytes, 0x00020000);
+    // stores go through descriptors as well: rows past P are dropped by the range check, no branch per piece
+    const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.P * C4 * 2, 0x00020000);
+    const auto rsT1n = __builtin_amdgcn_make_buffer_rsrc((void*)p.t1n, 0, p.P * CN * 2, 0x00020000);
 
     // chunk stream: per 64-channel slice s of y:  B_s = w3 rows [64 s, 64 s + 64) as [64 n][256 B];
     //                                             C_s,h = w1' rows [128 h, 128 h + 128), columns [64 s, 64 s + 64) as [128 n][128 B]
@@ -79,14 +86,14 @@ __global__ __launch_bounds__(256, 2) void btl_chain_kernel(const ChainArgs p) {
         char* dst = WB + buf * WB_BYTES + wave * 1024;
         const int s = id / CPS, which = id % CPS;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = u * 256 + tid;
+        for (int u = 0; u < 16 / NW; ++u) {
+            const int q = u * 64 * NW + tid;
             if (which == 0) {
                 const int n = q >> 4, c = (q & 15) ^ (n & 15);
-                glds16(rsW3, dst + u * 4096, (uint32_t)((s * 64 + n) * C + c * 8) * 2u);
+                glds16(rsW3, dst + u * 1024 * NW, (uint32_t)((s * 64 + n) * C + c * 8) * 2u);
             } else {
                 const int n = q >> 3, c = (q & 7) ^ ((n >> 1) & 7);
-                glds16(rsW1, dst + u * 4096, (uint32_t)(((which - 1) * 128 + n) * C4 + s * 64 + c * 8) * 2u);
+                glds16(rsW1, dst + u * 1024 * NW, (uint32_t)(((which - 1) * 128 + n) * C4 + s * 64 + c * 8) * 2u);
             }
         }
     };
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void btl_chain_kernel(const ChainArgs p) {
             const int row = wave * 32 + (q >> 3), c = (q & 7) ^ ((row >> 1) & 7);
             const int pr = p0 + row;
             const u32x4 v = lds128(XY + (wave * 32 + u * 8) * 128 + lane * 16);
-            if (pr < p.P) *reinterpret_cast<u32x4*>(p.y + (size_t)pr * C4 + s * 64 + c * 8) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsY, (uint32_t)(pr * C4 + s * 64 + c * 8) * 2u, 0, 0);
         }
         // ---- t1' += y slice . w1'[:, 64 s ..]^T ----------------------------------------------------------------
 #pragma unroll
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void btl_chain_kernel(const ChainArgs p) {
             const int r = wave * 32 + (q >> 4), c = (q & 15) ^ (r & 15);
             const int pr = p0 + r;
             const u32x4 v = lds128(A1 + (wave * 32 + u * 4) * 256 + lane * 16);
-            if (pr < p.P) *reinterpret_cast<u32x4*>(p.t1n + (size_t)pr * CN + h * 128 + c * 8) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsT1n, (uint32_t)(pr * CN + h * 128 + c * 8) * 2u, 0, 0);
         }
     }
 }
@@ -229,13 +236,18 @@ int sq_launch_bottleneck_chain_c128(const bf16_t* t2, const bf16_t* res, bf16_t*
     SQ_REQUIRE(w3_bytes >= (size_t)C4 * C * 2 && w1n_bytes >= (size_t)cn * C4 * 2, "bottleneck chain: weight extents");
     ChainArgs a;
     a.t2 = t2; a.res = res; a.y = y; a.t1n = t1n; a.w3 = w3; a.w1n = w1n; a.b3 = b3; a.b1n = b1n;
-    a.P = (int)P; a.tiles = (int)((P + 127) / 128);
+    static const int nw_env = getenv("SQ_CHAIN_NW") ? atoi(getenv("SQ_CHAIN_NW")) : 0;      // 4 or 8: experiment knob
+    const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (cn == 256 ? 8 : 4);               // measured: 304 vs 321 us / 249 vs 257 us
+    const int tp = 32 * nw;
+    a.P = (int)P; a.tiles = (int)((P + tp - 1) / tp);
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
     a.w3_bytes = clamp(w3_bytes); a.w1n_bytes = clamp(w1n_bytes);
     static bool attr = false;
     if (!attr) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4)));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4)));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(8)));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(8)));
         attr = true;
     }
     int prof = -1;
@@ -244,8 +256,13 @@ int sq_launch_bottleneck_chain_c128(const bf16_t* t2, const bf16_t* res, bf16_t*
         snprintf(name, sizeof(name), "btl_chain_c128_cn%d_P%lld", cn, P);
         prof = sq_prof_begin(name, 2.0 * P * (128.0 * 512 + 512.0 * cn), (double)P * 2.0 * (128 + 512 + 512 + cn) + 2.0 * (512 * 128 + cn * 512), stream);
     }
-    if (cn == 128) hipLaunchKernelGGL(btl_chain_kernel<128>, dim3(a.tiles), dim3(256), LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(btl_chain_kernel<256>, dim3(a.tiles), dim3(256), LDS_BYTES, stream, a);
+    if (nw == 4) {
+        if (cn == 128) hipLaunchKernelGGL((btl_chain_kernel<128, 4>), dim3(a.tiles), dim3(256), lds_bytes(4), stream, a);
+        else hipLaunchKernelGGL((btl_chain_kernel<256, 4>), dim3(a.tiles), dim3(256), lds_bytes(4), stream, a);
+    } else {
+        if (cn == 128) hipLaunchKernelGGL((btl_chain_kernel<128, 8>), dim3(a.tiles), dim3(512), lds_bytes(8), stream, a);
+        else hipLaunchKernelGGL((btl_chain_kernel<256, 8>), dim3(a.tiles), dim3(512), lds_bytes(8), stream, a);
+    }
     SQ_LAUNCH_CHECK();
     if (prof >= 0) sq_prof_end(prof, stream);
     return SQ_OK;

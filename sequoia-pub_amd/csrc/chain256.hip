@@ -76,6 +76,8 @@ __global__ __launch_bounds__(512, 1) void btl_chain256_kernel(const Chain256Args
     }
     const int p0 = t * 128;
     const auto rsRes = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.P * C4 * 2, 0x00020000);
+    const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.P * C4 * 2, 0x00020000);      // rows past P: stores dropped
+    const auto rsT1n = __builtin_amdgcn_make_buffer_rsrc((void*)p.t1n, 0, p.P * CN * 2, 0x00020000);
     const auto rsW3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
     const auto rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1n, 0, (int)p.w1n_bytes, 0x00020000);
 
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(512, 1) void btl_chain256_kernel(const Chain256Args
             const int row = 16 * h + u * 8 + (lane >> 3), c = lane & 7;
             const int pr = p0 + pg * 32 + row;
             const u32x4 v = lds128(xy + (pg * 2 + (c >> 2)) * 2048 + row * 64 + (((c & 3) ^ ((row >> 2) & 3)) << 4));
-            if (pr < p.P) *reinterpret_cast<u32x4*>(p.y + (size_t)pr * C4 + s * 64 + c * 8) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsY, (uint32_t)(pr * C4 + s * 64 + c * 8) * 2u, 0, 0);   // no branch per piece
         }
         if (j + 3 < NCHUNK) issue_chunk(j + 3);
         {
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, 1) void btl_chain256_kernel(const Chain256Args
             const int r = u * 4 + (lane >> 4), c = (lane & 15) ^ (r & 15);
             const int pr = p0 + pg * 32 + r;
             const u32x4 v = lds128(mine + u * 1024 + lane * 16);
-            if (pr < p.P) *reinterpret_cast<u32x4*>(p.t1n + (size_t)pr * CN + 128 * h + c * 8) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsT1n, (uint32_t)(pr * CN + 128 * h + c * 8) * 2u, 0, 0);
         }
     }
 }
