@@ -303,7 +303,10 @@ bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype) {
         min_k = k ? atoi(k) : 512;
     }
     const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.batch;
-    return a.K >= min_k && a.N % BN == 0 && tiles >= min_tiles;
+    // strided 1x1 convolutions (the downsample branches) gain from the 256-row tile already at K = 256: the layer-2 one
+    // 315 -> 265 us; plain K = 256 products with a residual epilogue lose (143 -> 182 us) and stay on gemm.hip
+    const int need_k = a.conv && a.res == nullptr ? (min_k < 256 ? min_k : 256) : min_k;
+    return a.K >= need_k && a.N % BN == 0 && tiles >= min_tiles;
 }
 
 namespace {
