@@ -186,7 +186,10 @@ __global__ void km_tol_kernel(const double* __restrict__ colvar, KmState* __rest
 // 32 blocks with 64 dependent K steps each).
 __global__ __launch_bounds__(256) void km_dgemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                           double* __restrict__ C, int M, int N, int K, long long sA,
-                                                          long long sB, long long sC, int ksl) {
+                                                          long long sB, long long sC, int ksl, int sym) {
+    // sym: A == B (Gram matrix): only the blocks on and above the diagonal are computed, each also stores its mirror
+    // image -- bit-exact, the products commute and the K order is the same on both sides of the diagonal
+    if (sym && blockIdx.x < blockIdx.y) return;
     __shared__ double sa[32][64 + 2];
     __shared__ double sb[32][64 + 2];
     const int slide = blockIdx.z / ksl, slice = blockIdx.z - slide * ksl;
@@ -201,20 +204,34 @@ __global__ __launch_bounds__(256) void km_dgemm_nt_kernel(const float* __restric
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-    // loader: thread -> (row = tid / 4 within 64, k4 = tid % 4 ... two passes of 16 k each)
+    // loader: thread -> (row = tid / 4 within 64, k4 = tid % 4 ... two passes of 16 k each).  The next K step's rows are
+    // fetched into registers before this step's MFMAs: a lone 64 x 64 block per CU otherwise spends its time waiting
+    // for one round of global loads per step (the 1000 x 1000 Gram matrix: 132 -> 75 us)
     const int lrow = tid >> 2, lk = (tid & 3) * 4;
-    for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
+    const bool arow = m0 + lrow < M, brow = n0 + lrow < N;
+    const float* ap = A + (size_t)(arow ? m0 + lrow : 0) * K;
+    const float* bp = B + (size_t)(brow ? n0 + lrow : 0) * K;
+    float4 va[2], vb[2];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int kk = k0 + half * 16 + lk;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (m0 + lrow < M && kk < k_hi) va = *reinterpret_cast<const float4*>(A + (size_t)(m0 + lrow) * K + kk);
-            if (n0 + lrow < N && kk < k_hi) vb = *reinterpret_cast<const float4*>(B + (size_t)(n0 + lrow) * K + kk);
+            va[half] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[half] = va[half];
+            if (arow && kk < k_hi) va[half] = *reinterpret_cast<const float4*>(ap + kk);
+            if (brow && kk < k_hi) vb[half] = *reinterpret_cast<const float4*>(bp + kk);
+        }
+    };
+    if (k_lo < k_hi) fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
             const int kr = half * 16 + lk;
-            sa[kr + 0][lrow] = va.x; sa[kr + 1][lrow] = va.y; sa[kr + 2][lrow] = va.z; sa[kr + 3][lrow] = va.w;
-            sb[kr + 0][lrow] = vb.x; sb[kr + 1][lrow] = vb.y; sb[kr + 2][lrow] = vb.z; sb[kr + 3][lrow] = vb.w;
+            sa[kr + 0][lrow] = va[half].x; sa[kr + 1][lrow] = va[half].y; sa[kr + 2][lrow] = va[half].z; sa[kr + 3][lrow] = va[half].w;
+            sb[kr + 0][lrow] = vb[half].x; sb[kr + 1][lrow] = vb[half].y; sb[kr + 2][lrow] = vb[half].z; sb[kr + 3][lrow] = vb[half].w;
         }
         __syncthreads();
+        if (k0 + 32 < k_hi) fetch(k0 + 32);
 #pragma unroll
         for (int ks = 0; ks < 32; ks += 4) {
             const int k = ks + (lane >> 4);
@@ -239,20 +256,32 @@ __global__ __launch_bounds__(256) void km_dgemm_nt_kernel(const float* __restric
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
                 const int n = n0 + wn * 32 + j * 16 + (lane & 15);
-                if (m < M && n < N) C[(size_t)m * N + n] = acc[i][j][r];
+                if (m < M && n < N) {
+                    C[(size_t)m * N + n] = acc[i][j][r];
+                    if (sym && blockIdx.x != blockIdx.y) C[(size_t)n * N + m] = acc[i][j][r];
+                }
             }
 }
 
 // ------------------------------------------------------------------------------------------
 // 3. k-means++ seeding: one workgroup per slide, all k-1 dependent steps inside the kernel
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float seed_dist(const double* G, int n, int c, int j, double njj) {
-    // pairwise.py:647-651: d = -2 X.Y^T; d += XX; d += YY; cast fp32; max(., 0)   (njj = |x_j|^2 = G[j][j])
-    double d = -2.0 * G[(size_t)c * n + j];
-    d += G[(size_t)c * n + c];
-    d += njj;
-    const float f = (float)d;
-    return f > 0.f ? f : 0.f;
+// Squared distances of the seeding step as fp32, once for all pairs: exactly pairwise.py:647-651 per element
+// (d = -2 X.Y^T; d += XX; d += YY in fp64 from the Gram matrix; cast fp32; max(., 0)), row c = distances from point c.
+// The seeding kernel then reads 4-byte distances (16 bytes per thread and candidate) instead of rebuilding them from
+// 8-byte Gram entries inside its 99 dependent steps.
+__global__ __launch_bounds__(256) void km_dist_f32_kernel(const double* __restrict__ Gall, float* __restrict__ Dall, int n) {
+    const int c = blockIdx.x;
+    const double* G = Gall + (size_t)blockIdx.y * n * n;
+    float* Dm = Dall + (size_t)blockIdx.y * n * n;
+    const double gcc = G[(size_t)c * n + c];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double d = -2.0 * G[(size_t)c * n + j];
+        d += gcc;
+        d += G[(size_t)j * n + j];
+        const float f = (float)d;
+        Dm[(size_t)c * n + j] = f > 0.f ? f : 0.f;
+    }
 }
 
 // One step = scan -> candidates -> candidate potentials -> choice, i.e. three block-wide exchanges and ONE round of
@@ -261,23 +290,22 @@ __device__ __forceinline__ float seed_dist(const double* G, int n, int c, int j,
 // for the `closest` update (no second read of G).  Arithmetic (scan association, reduction orders) is unchanged from
 // the first version of this kernel, results are bit-identical.
 template <int PTS>   // points per thread (n <= PTS * blockDim.x)
-__global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __restrict__ Gall, const double* __restrict__ uniforms,
+__global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const float* __restrict__ Dall, const double* __restrict__ uniforms,
                                                              int first, int n, int k, int trials, int* __restrict__ seeds) {
     __shared__ double sh[2][16 * KM_MAX_TRIALS];
     __shared__ int shi[2][16 * KM_MAX_TRIALS];
     __shared__ double scan_w[2][16];
-    const double* G = Gall + (size_t)blockIdx.x * n * n;
+    const float* Dm = Dall + (size_t)blockIdx.x * n * n;
     int* out = seeds + (size_t)blockIdx.x * k;
+    const bool vec4 = PTS == 4 && (n & 3) == 0;        // a thread's four points are one aligned 16-byte load
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
 
     // thread owns the CONTIGUOUS points [tid*PTS, tid*PTS+PTS) so the scan is a plain blocked scan
     float closest[PTS];
-    double nrm[PTS];
 #pragma unroll
     for (int q = 0; q < PTS; ++q) {
         const int j = tid * PTS + q;
-        nrm[q] = j < n ? G[(size_t)j * n + j] : 0.0;
-        closest[q] = j < n ? seed_dist(G, n, first, j, nrm[q]) : 0.f;
+        closest[q] = j < n ? Dm[(size_t)first * n + j] : 0.f;
     }
     float pot;
     {
@@ -324,37 +352,44 @@ __global__ __launch_bounds__(KM_THREADS) void km_seed_kernel(const double* __res
         }
         __syncthreads();
         int cand[KM_MAX_TRIALS];
-        double cn[KM_MAX_TRIALS];                        // |x_cand|^2 = G[cand][cand]
 #pragma unroll
         for (int t = 0; t < KM_MAX_TRIALS; ++t) {
             int r = 0;
             if (t < trials)
                 for (int i = 0; i < nw; ++i) r += shi[par][i * KM_MAX_TRIALS + t];
             cand[t] = r > n - 1 ? n - 1 : r;
-            cn[t] = t < trials ? G[(size_t)cand[t] * n + cand[t]] : 0.0;
         }
         // distances to the candidates (one round of loads for all trials), potentials
         float dc[KM_MAX_TRIALS][PTS];
         double p[KM_MAX_TRIALS];
 #pragma unroll
         for (int t = 0; t < KM_MAX_TRIALS; ++t) {
+            if (t < trials) {
+                const float* row = Dm + (size_t)cand[t] * n;
+                if constexpr (PTS == 4) {
+                    if (vec4 && tid * 4 < n) {
+                        const float4 v = *reinterpret_cast<const float4*>(row + tid * 4);
+                        dc[t][0] = v.x; dc[t][1] = v.y; dc[t][2] = v.z; dc[t][3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < PTS; ++q) dc[t][q] = tid * PTS + q < n ? row[tid * PTS + q] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PTS; ++q) dc[t][q] = tid * PTS + q < n ? row[tid * PTS + q] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) {
             p[t] = 0.0;
             if (t < trials) {
 #pragma unroll
-                for (int q = 0; q < PTS; ++q) {
-                    const int j = tid * PTS + q;
-                    float f = 0.f;
-                    if (j < n) {
-                        // pairwise.py:647-651: d = -2 X.Y^T; d += XX; d += YY; cast fp32; max(., 0)
-                        double dd = -2.0 * G[(size_t)cand[t] * n + j];
-                        dd += cn[t];
-                        dd += nrm[q];
-                        f = (float)dd;
-                        f = f > 0.f ? f : 0.f;
-                        p[t] += (double)fminf(closest[q], f);
-                    }
-                    dc[t][q] = f;
-                }
+                for (int q = 0; q < PTS; ++q)
+                    if (tid * PTS + q < n) p[t] += (double)fminf(closest[q], dc[t][q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < PTS; ++q) dc[t][q] = 0.f;
             }
         }
 #pragma unroll
@@ -426,35 +461,36 @@ __global__ __launch_bounds__(64) void km_center_norms_kernel(const float* __rest
 
 // labels[j] = argmin_c (|c|^2 - 2 x_j.c), strict '<' (first minimum); dots from the fp64 GEMM as ksl planes of
 // [k centres][n points] (a thread walks the centres of ITS point: consecutive threads read consecutive doubles)
-__global__ __launch_bounds__(256) void km_assign_kernel(const double* __restrict__ dots, const double* __restrict__ cnorm, int* __restrict__ labels,
-                                                        const KmState* __restrict__ st, int n, int D, int k, int force, int ksl) {
-    // block = 64 points x 4 centre groups (wave g walks centres [g*k/4, (g+1)*k/4) of its 64 points, five centres'
-    // loads in flight at a time); the four partial minima are merged in centre order, which keeps the first minimum
+__global__ __launch_bounds__(1024) void km_assign_kernel(const double* __restrict__ dots, const double* __restrict__ cnorm, int* __restrict__ labels,
+                                                         const KmState* __restrict__ st, int n, int D, int k, int force, int ksl) {
+    // block = 64 points x 16 centre groups (wave g walks centres [g*k/16, (g+1)*k/16) of its 64 points, all of their
+    // slice loads in flight together); the partial minima are merged in centre order, which keeps the first minimum
+    constexpr int G = 16, CB = 7;
     __shared__ double cn[KM_MAX_K];
-    __shared__ double bval[4][64];
-    __shared__ int blab[4][64];
+    __shared__ double bval[G][64];
+    __shared__ int blab[G][64];
     const int s = blockIdx.y;
     if (st[s].done && !force) return;
     for (int c = threadIdx.x; c < k; c += blockDim.x) cn[c] = cnorm[(size_t)s * k + c];
     __syncthreads();
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
-    const int c_lo = g * k / 4, c_hi = (g + 1) * k / 4;
+    const int c_lo = g * k / G, c_hi = (g + 1) * k / G;
     const size_t plane = (size_t)k * n;
     const double* dr = dots + (size_t)s * ksl * plane + (j < n ? j : 0);
     double best = 0.0;
     int lab = -1;
-    for (int c0 = c_lo; c0 < c_hi; c0 += 5) {
-        double dot[5];
+    for (int c0 = c_lo; c0 < c_hi; c0 += CB) {
+        double dot[CB];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
+        for (int u = 0; u < CB; ++u) {
             const int c = c0 + u < c_hi ? c0 + u : c_hi - 1;
             double a = dr[(size_t)c * n];
             for (int q = 1; q < ksl; ++q) a += dr[q * plane + (size_t)c * n];
             dot[u] = a;
         }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
+        for (int u = 0; u < CB; ++u) {
             const int c = c0 + u;
             if (c < c_hi) {
                 const double v = cn[c] - 2.0 * dot[u];
@@ -469,7 +505,7 @@ __global__ __launch_bounds__(256) void km_assign_kernel(const double* __restrict
         double b = bval[0][lane];
         int l = blab[0][lane];
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
+        for (int q = 1; q < G; ++q)
             if (blab[q][lane] >= 0 && (l < 0 || bval[q][lane] < b)) { b = bval[q][lane]; l = blab[q][lane]; }
         labels[(size_t)s * n + j] = l;
     }
@@ -657,9 +693,10 @@ __global__ void km_restore_strict_kernel(int* __restrict__ labels, const int* __
 
 __global__ void km_count_done_kernel(const KmState* __restrict__ st, int S, int* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int d = 0;
-        for (int s = 0; s < S; ++s) d += st[s].done;
-        *out = d;
+        int d = 0, q = 0;
+        for (int s = 0; s < S; ++s) { d += st[s].done; q += st[s].strict; }
+        out[0] = d;
+        out[1] = q;
     }
 }
 
@@ -683,6 +720,7 @@ __global__ void km_cluster_means_kernel(const float* __restrict__ X, const int* 
 struct KmBufs {
     float* Xc; double* colvar; double* G; float* centers; float* centers2; double* shift_part; double* dots; double* sums; double* weights; double* dist;
     int* seeds; int* labels_old; int* members; int* offsets; int* done_count; KmState* st;
+    float* dist32;
     size_t bytes;
 };
 
@@ -705,6 +743,7 @@ void km_bufs(int S, int n, int D, int k, char* base, KmBufs* o) {
     o->offsets = (int*)take((size_t)S * (k + 1) * 4);
     o->done_count = (int*)take(256);
     o->st = (KmState*)take((size_t)S * sizeof(KmState));
+    o->dist32 = (float*)take((size_t)S * n * n * 4);
     o->bytes = sq_align_up(off, 256);
 }
 
@@ -740,17 +779,19 @@ extern "C" int sq_kmeans_fit(const float* X, int S, int n, int D, int k, int fir
     SQ_LAUNCH_CHECK();
     // Gram matrix of the centred data (fp64)
     hipLaunchKernelGGL(km_dgemm_nt_kernel, dim3((n + 63) / 64, (n + 63) / 64, S), dim3(256), 0, st, b.Xc, b.Xc, b.G, n, n, D,
-                       (long long)n * D, (long long)n * D, (long long)n * n, 1);
+                       (long long)n * D, (long long)n * D, (long long)n * n, 1, 1);
+    SQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(km_dist_f32_kernel, dim3(n, S), dim3(256), 0, st, b.G, b.dist32, n);
     SQ_LAUNCH_CHECK();
     const bool few_waves = !sq_env_flag("SQ_KM_SEED_1024");
     if (n <= KM_THREADS && few_waves)       // 4 waves x 4 points per thread: cheaper barriers and wave exchanges than 16 waves x 1
-        hipLaunchKernelGGL(km_seed_kernel<4>, dim3(S), dim3(256), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
+        hipLaunchKernelGGL(km_seed_kernel<4>, dim3(S), dim3(256), 0, st, b.dist32, uniforms, first_center, n, k, n_local_trials, b.seeds);
     else if (n <= KM_THREADS)
-        hipLaunchKernelGGL(km_seed_kernel<1>, dim3(S), dim3(KM_THREADS), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
+        hipLaunchKernelGGL(km_seed_kernel<1>, dim3(S), dim3(KM_THREADS), 0, st, b.dist32, uniforms, first_center, n, k, n_local_trials, b.seeds);
     else if (n <= 2 * KM_THREADS)
-        hipLaunchKernelGGL(km_seed_kernel<2>, dim3(S), dim3(KM_THREADS), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
+        hipLaunchKernelGGL(km_seed_kernel<2>, dim3(S), dim3(KM_THREADS), 0, st, b.dist32, uniforms, first_center, n, k, n_local_trials, b.seeds);
     else
-        hipLaunchKernelGGL(km_seed_kernel<4>, dim3(S), dim3(KM_THREADS), 0, st, b.G, uniforms, first_center, n, k, n_local_trials, b.seeds);
+        hipLaunchKernelGGL(km_seed_kernel<4>, dim3(S), dim3(KM_THREADS), 0, st, b.dist32, uniforms, first_center, n, k, n_local_trials, b.seeds);
     SQ_LAUNCH_CHECK();
     if (seed_indices) SQ_HIP_CHECK(hipMemcpyAsync(seed_indices, b.seeds, (size_t)S * k * 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(km_gather_centers_kernel, dim3(k, S), dim3(256), 0, st, b.Xc, b.seeds, b.centers, n, D, k);
@@ -763,19 +804,20 @@ extern "C" int sq_kmeans_fit(const float* X, int S, int n, int D, int k, int fir
     auto e_step = [&](int force) -> int {
         // dots[slice][centre][point] = centres . points (fp64), K sliced so that the launch fills the chip
         hipLaunchKernelGGL(km_dgemm_nt_kernel, dim3((n + 63) / 64, (k + 63) / 64, S * ksl), dim3(256), 0, st, cur, b.Xc, b.dots, k, n, D,
-                           (long long)k * D, (long long)n * D, (long long)k * n, ksl);
+                           (long long)k * D, (long long)n * D, (long long)k * n, ksl, 0);
         SQ_LAUNCH_CHECK();
         hipLaunchKernelGGL(km_center_norms_kernel, dim3(k, S), dim3(64), 0, st, cur, b.shift_part + (size_t)S * k, b.st, D, k, force);
         SQ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(km_assign_kernel, dim3((n + 63) / 64, S), dim3(256), 0, st, b.dots, b.shift_part + (size_t)S * k, labels, b.st, n, D, k, force, ksl);
+        hipLaunchKernelGGL(km_assign_kernel, dim3((n + 63) / 64, S), dim3(1024), 0, st, b.dots, b.shift_part + (size_t)S * k, labels, b.st, n, D, k, force, ksl);
         SQ_LAUNCH_CHECK();
         hipLaunchKernelGGL(km_members_kernel, dim3(S), dim3(KM_THREADS), 0, st, labels, b.members, b.offsets, b.st, n, k, force);
         SQ_LAUNCH_CHECK();
         return SQ_OK;
     };
     int it = 0;
+    int done[2] = {0, 0};            // slides finished / of those, strictly converged (labels unchanged)
     while (it < max_iter) {
-        const int burst = it == 0 ? 3 : 4;      // iterations between host checks of the done flags
+        const int burst = it == 0 ? 2 : 4;      // iterations between host checks of the done flags
         for (int q = 0; q < burst && it < max_iter; ++q, ++it) {
             if (int e = e_step(0)) return e;
             hipLaunchKernelGGL(km_sums_kernel, dim3(k, S), dim3(256), 0, st, b.Xc, b.members, b.offsets, b.sums, b.st, n, D, k);
@@ -791,16 +833,17 @@ extern "C" int sq_kmeans_fit(const float* X, int S, int n, int D, int k, int fir
         }
         hipLaunchKernelGGL(km_count_done_kernel, dim3(1), dim3(64), 0, st, b.st, S, b.done_count);
         SQ_LAUNCH_CHECK();
-        int done = 0;
-        SQ_HIP_CHECK(hipMemcpyAsync(&done, b.done_count, 4, hipMemcpyDeviceToHost, st));
+        SQ_HIP_CHECK(hipMemcpyAsync(done, b.done_count, 8, hipMemcpyDeviceToHost, st));
         SQ_HIP_CHECK(hipStreamSynchronize(st));
-        if (done == S) break;
+        if (done[0] == S) break;
     }
     // final E-step for the slides that did not converge strictly (labels must match the final centres).
     // For strictly converged slides the labels of the last E-step are already the answer and the
     // centres moved by a label-preserving update, so re-running the E-step for everyone is only
     // correct for the non-strict ones: the assign kernel is forced, then strict slides are restored.
-    {
+    // When every slide converged strictly (the common case) nothing is left to do: labels and member lists are
+    // those of the last E-step (_kmeans.py: the extra E-step runs only `if not strict_convergence`).
+    if (!(done[0] == S && done[1] == S)) {
         // strict slides keep labels (== labels_old after the last update); non-strict get a fresh E-step
         if (int e = e_step(1)) return e;
         // restore labels of strict slides from labels_old and rebuild their member lists

@@ -23,6 +23,23 @@ def seeding_draws(n_samples, n_clusters, random_state=0):
     return first, u
 
 
+_draws_cache = {}
+
+
+def _device_draws(n_samples, n_clusters, random_state, dev):
+    """The draw sequence depends only on (n, k, seed): the reference clusters every slide with the same
+    ``random_state`` (kmean_features.py:96), so the host RNG walk and the (synchronous, pageable) upload are paid once
+    per shape instead of once per slide -- 60-80 us of a 1.6 ms call."""
+    key = (int(n_samples), int(n_clusters), int(random_state), str(dev))
+    hit = _draws_cache.get(key)
+    if hit is None:
+        first, u = seeding_draws(n_samples, n_clusters, random_state)
+        if len(_draws_cache) >= 64:
+            _draws_cache.clear()
+        hit = _draws_cache[key] = (first, torch.from_numpy(u).to(dev), u.shape[1])      # blocking copy: visible to every stream
+    return hit
+
+
 def kmeans_fit_batch(X, n_clusters=100, random_state=0, max_iter=300, tol=1e-4, want_means=True):
     """X: f32 [S, n, D] CUDA tensor (S slides with the same patch count).  Returns dict of CUDA tensors:
     labels i32 [S, n], cluster_features f32 [S, k, D], indices i32 [S, k], n_iter i32 [S]."""
@@ -34,8 +51,7 @@ def kmeans_fit_batch(X, n_clusters=100, random_state=0, max_iter=300, tol=1e-4, 
     X = X.to(torch.float32).contiguous()
     S, n, D = X.shape
     dev = X.device
-    first, u = seeding_draws(n, n_clusters, random_state)
-    u_dev = torch.from_numpy(u).to(dev)
+    first, u_dev, trials = _device_draws(n, n_clusters, random_state, dev)
     labels = torch.empty(S, n, dtype=torch.int32, device=dev)
     means = torch.empty(S, n_clusters, D, dtype=torch.float32, device=dev) if want_means else None
     seeds = torch.empty(S, n_clusters, dtype=torch.int32, device=dev)
@@ -43,7 +59,7 @@ def kmeans_fit_batch(X, n_clusters=100, random_state=0, max_iter=300, tol=1e-4, 
     need = _lib.lib().sq_kmeans_workspace_bytes(S, n, D, n_clusters)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().sq_kmeans_fit(_lib.ptr(X), S, n, D, n_clusters, first, _lib.ptr(u_dev), u.shape[1], max_iter,
+        _lib.check(_lib.lib().sq_kmeans_fit(_lib.ptr(X), S, n, D, n_clusters, first, _lib.ptr(u_dev), trials, max_iter,
                                             float(tol), _lib.ptr(labels), _lib.ptr(means), _lib.ptr(seeds), _lib.ptr(n_iter),
                                             _lib.ptr(ws), need, _lib.stream_ptr(dev)))
     return dict(labels=labels, cluster_features=means, indices=seeds, n_iter=n_iter)
