@@ -128,8 +128,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs p) {
     const int e_c8 = tid % BN8, e_rbase = tid / BN8;
     const int e_n = n0 + e_c8 * 8;
     const int e_cnt = min(8, p.N - e_n);
-    const bool fast = EPI == 0 && p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && !p.Cpre && !p.C2 && !p.gelu_grad_of &&
-                      p.act != SQ_ACT_GELU && !p.ln64_g;
+    const bool fast = (EPI == 0 || EPI == 1) && p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && !p.Cpre && !p.gelu_grad_of && !p.ln64_g;
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -270,7 +269,10 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs p) {
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (p.alpha * v[e] + bias8[e]) + aux[u][e];
-            if (p.act == SQ_ACT_RELU) {
+            if ((EPI & 1) && p.act == SQ_ACT_GELU) {                     // same erf form as epi_apply<EPI, true>
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sq_gelu<true>(v[e]);
+            } else if (p.act == SQ_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
@@ -279,9 +281,9 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs p) {
                 *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
             }
-            if (c16p)
-                *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) =
-                    u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            const u32x4 packed = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            if (c16p) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = packed;
+            if (p.C2) *reinterpret_cast<u32x4*>(p.C2 + (long long)z * p.sC2 + (long long)m * p.ldc2 + e_n) = packed;   // bf16 operand copy
         }
     }
 }
@@ -292,9 +294,9 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(const GemmArgs p) {
 // tiles to keep 256 CUs (one block each) busy for at least ~2 rounds
 bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype) {
     if (dtype != SQ_BF16 || a.splitk != 1 || a.ln64_g) return false;
-    // only the epilogues the prefetching fast path covers (bias, residual, ReLU): with one block per CU nothing hides a
-    // generic epilogue, and the ViS products (GELU / extra copies / row bias) measured 2x slower here than on gemm.hip
-    if (a.rowbias || a.Cpre || a.C2 || a.gelu_grad_of || a.act == SQ_ACT_GELU) return false;
+    // only the epilogues the prefetching fast path covers (bias, residual, ReLU / GELU, a second bf16 copy): with one
+    // block per CU nothing hides a generic epilogue -- row-bias / pre-activation-copy products measured 2x slower here
+    if (a.rowbias || a.Cpre || a.gelu_grad_of) return false;
     static int min_tiles = -1, min_k = -1;
     if (min_tiles < 0) {
         const char* e = getenv("SQ_GEMM_RING_MIN_TILES");
