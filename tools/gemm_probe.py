@@ -59,6 +59,14 @@ if __name__ == "__main__":
                         (24500, 512, 4608), (24500, 2048, 1024), (392000, 128, 1152), (98000, 1024, 256), (6400, 1024, 1024)]:
             probe(M, N, K, _lib.SQ_BF16, tiles=(22, 44, 33), dbgs=(0,))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "uni":
+        for M, N, K in [(50432, 4096, 1024), (50432, 1024, 4096), (50432, 3072, 1024), (50432, 1024, 1024), (102400, 2048, 2048)]:
+            probe(M, N, K, _lib.SQ_BF16, tiles=(22, 33, 44), dbgs=(0,))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "l4":
+        for M, N, K in [(24500, 512, 4608), (24500, 2048, 512), (24500, 512, 2048), (24500, 2048, 1024), (98000, 512, 1024), (6400, 1024, 1024)]:
+            probe(M, N, K, _lib.SQ_BF16, tiles=(0, 22, 21, 12, 33), dbgs=(0,))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "resnet":
         for M, N, K in [(39200, 1024, 256), (9800, 2048, 512), (39200, 256, 1024), (156800, 512, 128), (156800, 128, 512),
                         (9800, 512, 2048), (627200, 64, 256), (627200, 256, 64), (39200, 512, 1024)]:
