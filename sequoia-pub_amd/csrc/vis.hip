@@ -213,7 +213,8 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             GemmArgs g; g.A = w.Lf[s]; g.lda = HD; g.a_bytes = (size_t)M * HD * es; g.sA = SQ_HEAD_DIM;
             g.B = W(L.c_w); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
             g.rowbias = w.Cs[s]; g.ldrb = HD; g.sRb = SQ_HEAD_DIM; g.rows_per_group = N;
-            g.act = SQ_ACT_GELU; g.Cpre = w.P[s]; g.pre_dtype = sq_vis_preact_dtype(dtype); g.ldpre = HD; g.sPre = SQ_HEAD_DIM;
+            g.act = SQ_ACT_GELU;
+            if (save) { g.Cpre = w.P[s]; g.pre_dtype = sq_vis_preact_dtype(dtype); g.ldpre = HD; g.sPre = SQ_HEAD_DIM; }   // pre-activations: backward only
             g.C = w.O[s]; g.out_dtype = dtype; g.ldc = HD; g.sC = SQ_HEAD_DIM;
             g.M = M; g.N = SQ_HEAD_DIM; g.K = SQ_HEAD_DIM; g.batch = H;
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
@@ -228,7 +229,8 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
         {   // H1 = GELU(Y W1^T + b1)
             GemmArgs g; g.A = w.Y[s]; g.lda = D; g.a_bytes = (size_t)M * D * es;
             g.B = W(L.ff1_w); g.ldb = D; g.b_bytes = Wrem(L.ff1_w); g.bias = Pf(L.ff1_b);
-            g.act = SQ_ACT_GELU; g.Cpre = w.U[s]; g.pre_dtype = sq_vis_preact_dtype(dtype); g.ldpre = D;
+            g.act = SQ_ACT_GELU;
+            if (save) { g.Cpre = w.U[s]; g.pre_dtype = sq_vis_preact_dtype(dtype); g.ldpre = D; }
             g.C = w.H1[s]; g.out_dtype = dtype; g.ldc = D; g.M = M; g.N = D; g.K = D;
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
