@@ -5,11 +5,14 @@
 // of fabric traffic: both are bound by bytes, not by the matrix pipes.
 //
 // Same construction as the fused tail of the 56 x 56 stage (bottleneck.hip) without its 3x3 stage:
-//   * tile = 128 pixels, 4 waves, wave w = rows [32w, 32w + 32) x all channels; products transposed (lane = pixel);
+//   * tile = 32 NW pixels, NW = 4 or 8 waves, wave w = rows [32w, 32w + 32) x all channels; products transposed (lane =
+//     pixel);
 //   * the t2 tile [128][C = 128] stays in LDS; y is produced in slices of 64 channels: slice = t2 . w3[slice]^T
 //     (16 MFMAs per wave), + bias + identity slice (LDS-DMA'd into the wave's own rows, replaced in place by y),
 //     stored with 16-byte row-major accesses, then immediately contracted with w1'[:, slice] into the t1' accumulators;
-//   * weights stream through two 16 KiB buffers, one barrier per chunk; 80 KiB per block, two blocks per CU.
+//   * weights stream through two 16 KiB buffers, one barrier per chunk; NW = 4: 80 KiB per block, two blocks per CU
+//     (used for a 128-wide next layer); NW = 8: 128 KiB, one block per CU, half the weight re-streaming (256-wide);
+//   * outputs leave through buffer descriptors: rows past P are dropped by the range check, no branch per store.
 // Bit-identical to the two GEMM launches it replaces (same bf16 rounding of y, same ascending-K accumulation).
 #include "gemm.h"
 
