@@ -284,6 +284,25 @@ int sq_uni_forward(const sq_uni_config* cfg, int dtype, const float* params, con
                    const uint8_t* patches_u8, const float* patches_f32_nchw, int n_patches, float* out, void* workspace,
                    size_t workspace_bytes, sq_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * HE2RNA comparator (/root/reference/src/he2rna.py:42-106, built by src/pretrain_gtex.py:102-105).
+ * The per-tile MLP (1x1 Conv1d layers, he2rna.py:101-106) is sq_linear on the token-major tensor [B * N, C]; these
+ * entry points are forward_fixed_k's masking and top-k aggregation (:93-99) and its gradient.
+ *   sq_he2rna_tile_mask : mask[row] = 1 if max_c x_tokens[row, c] > 0 else 0           (:94-95; f32 [n_rows, C])
+ *   sq_he2rna_topk_mean : out[b, g] = scale * sum_i  (sum_{j<k_i} sorted_desc(s[b, :, g])[j] * mask[b, j]) /
+ *                         (sum_{j<k_i} mask[b, j]),   s[b, n, g] = scores[b, n, g] * mask[b, n]   (:96-98);
+ *                         scale = 1 for one k (training, :85-86), 1 / len(ks) for the eval mean over ks (:88-91).
+ *                         scores f32 [B, N, ld_scores >= G] token-major, N <= 128 tiles, 1 <= k_i <= N, out f32 [B, G].
+ *                         0/0 (the first k tiles of a slide all masked) is NaN, as in the reference.
+ *   sq_he2rna_topk_mean_bwd : grad_scores f32 [B, N, ld_grad >= G] from grad_out f32 [B, G] (columns >= G untouched).
+ * ---------------------------------------------------------------------------------------------------------- */
+int sq_he2rna_tile_mask(const float* x_tokens, int n_rows, int n_channels, float* mask, sq_stream_t stream);
+int sq_he2rna_topk_mean(const float* scores, int ld_scores, const float* mask, const int32_t* ks, int n_ks, float scale,
+                        float* out, int batch, int n_tiles, int n_genes, sq_stream_t stream);
+int sq_he2rna_topk_mean_bwd(const float* scores, int ld_scores, const float* mask, const int32_t* ks, int n_ks, float scale,
+                            const float* grad_out, float* grad_scores, int ld_grad, int batch, int n_tiles, int n_genes,
+                            sq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,6 +137,12 @@ def _declare(lib):
     lib.sq_prof_report.argtypes = [ctypes.c_char_p, sz]
     lib.sq_linear.restype = i32
     lib.sq_linear.argtypes = [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp, sz, vp]
+    lib.sq_he2rna_tile_mask.restype = i32
+    lib.sq_he2rna_tile_mask.argtypes = [vp, i32, i32, vp, vp]
+    lib.sq_he2rna_topk_mean.restype = i32
+    lib.sq_he2rna_topk_mean.argtypes = [vp, i32, vp, vp, i32, f32, vp, i32, i32, i32, vp]
+    lib.sq_he2rna_topk_mean_bwd.restype = i32
+    lib.sq_he2rna_topk_mean_bwd.argtypes = [vp, i32, vp, vp, i32, f32, vp, vp, i32, i32, i32, i32, vp]
     lib.sq_linear_weight_grad.restype = i32
     lib.sq_linear_weight_grad.argtypes = [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, sz, vp]
     lib.sq_cast_f32_to_bf16.restype = i32

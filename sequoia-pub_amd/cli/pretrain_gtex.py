@@ -1,6 +1,7 @@
 """Pre-training on a whole cohort without validation split -- counterpart of /root/reference/src/pretrain_gtex.py
 (same flags; `train(..., phases=['train'])`, AdamW lr 3e-3, checkpoint `model_best.pt` under
-`<save_dir>/<date>_<exp_name>/`).  `--model he2rna` (the MLP baseline, SURVEY: out of scope) is rejected."""
+`<save_dir>/<date>_<exp_name>/`).  `--model he2rna` builds the MLP comparator of pretrain_gtex.py:102-105 and trains it
+with he2rna.fit (:118-120: Adam lr 3e-3, no validation, whole model pickled as `model.pt`)."""
 import argparse
 import datetime
 import os
@@ -23,7 +24,7 @@ def main(argv=None):
     p.add_argument('--feature_path', type=str, default="/examples/features", help='path to resnet and clustered features')
     p.add_argument('--exp_name', type=str, default="exp", help='Experiment name used to create saved model name')
     p.add_argument('--log', type=int, default=0, help='whether to log the loss')
-    p.add_argument('--model', type=str, default='vis', help='"vit" for transformer aggregation or "vis" for linearized transformer aggregation')
+    p.add_argument('--model', type=str, default='vis', help='model to pretrain, "he2rna" for MLP aggregation, "vit" for transformer aggregation or "vis" for linearized transformer aggregation')
     p.add_argument('--seed', type=int, default=99)
     p.add_argument('--num_epochs', type=int, default=200)
     p.add_argument('--batch_size', type=int, default=16)
@@ -63,11 +64,21 @@ def main(argv=None):
         from ..vit import ViT
         model = ViT(num_outputs=dataset.num_genes, dim=dataset.feature_dim, depth=6, heads=16, mlp_dim=2048, dim_head=64,
                     device=str(device), compute_dtype=args.compute_dtype)
+    elif args.model == 'he2rna':
+        from ..he2rna import HE2RNA, fit
+        model = HE2RNA(input_dim=dataset.feature_dim, layers=[256, 256], ks=[1, 2, 5, 10, 20, 50, 100],
+                       output_dim=dataset.num_genes, device=str(device))
     else:
-        raise SystemExit('please specify correct model name, "vit" or "vis" (the HE2RNA baseline is not part of this library)')
+        raise SystemExit('please specify correct model name, "vit" or "he2rna"')
     if args.checkpoint is not None:
         model.load_state_dict(torch.load(args.checkpoint, map_location='cpu'))
     model = model.to(device)
+    if args.model == 'he2rna':
+        # pretrain_gtex.py:118-120 (200 epochs by default; --quick caps the run the way it does for the other models)
+        model = fit(model=model, lr=3e-3, train_loader=dataloader, valid_loader=None, test_loader=None,
+                    params={'max_epochs': args.num_epochs} if args.quick else {}, fold=None, optimizer=None, path=save_dir)
+        print('Finished pre-training')
+        return model, save_dir
     model = train(model, {'train': dataloader}, None, num_epochs=args.num_epochs, phases=['train'], save_dir=save_dir, run=run,
                   lr=3e-3)
     print('Finished pre-training')

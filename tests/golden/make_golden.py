@@ -429,8 +429,40 @@ def gold_pipeline():
     print("pipeline: n_iter", km.n_iter_, "pred mean |.|", float(np.abs(pred).mean()), "clusters min size", int(np.bincount(labels).min()))
 
 
+def gold_he2rna():
+    """src/he2rna.py:42-106 (HE2RNA, the benchmark comparator of pretrain_gtex.py:102-105): seeded weights and inputs,
+    eval-mode forward (mean over ks), forward_fixed_k for three k, and the autograd gradients of one fixed-k forward
+    (dropout off).  Inputs have zero tiles (mask) and more channels than input_dim (the leading ones are cut, :102)."""
+    from src.he2rna import HE2RNA
+    g = torch.Generator().manual_seed(5)
+    B, extra, D, N, G = 4, 3, 32, 100, 50
+    ks = [1, 2, 5, 10, 20, 50, 100]
+    model = HE2RNA(input_dim=D, output_dim=G, layers=[16, 16], ks=ks, dropout=0.0, device="cpu")
+    sd = {k: torch.randn(v.shape, generator=g) * (0.3 if "weight" in k else 0.1) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    x = torch.randn(B, extra + D, N, generator=g)
+    x[0, :, 90:] = 0.0                               # padded tiles: mask 0
+    x[1, :, 5:60] = -torch.rand(extra + D, 55, generator=g)     # all-negative tiles: max <= 0 -> masked as well
+    x[2, :, 1::3] = 0.0
+    x[3, :, :2] = 0.0                                # first tiles masked: sum(mask[:k]) = 0 for k <= 2 -> 0/0 = NaN (reference quirk)
+    model.eval()
+    with torch.no_grad():
+        pred_eval = model(x).numpy()
+        fixed = {k: model.forward_fixed_k(x, k).numpy() for k in (1, 10, 100)}
+    r = torch.randn(B, G, generator=g)
+    model.zero_grad()
+    xg = x.clone().requires_grad_(True)
+    (model.forward_fixed_k(xg, 20) * r).sum().backward()
+    grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
+    out = dict(x=x.numpy(), r=r.numpy(), pred_eval=pred_eval, ks=np.array(ks), grad_x=xg.grad.numpy().copy(),
+               **{"fixed_%d" % k: v for k, v in fixed.items()}, **{"w_" + k: v.numpy() for k, v in sd.items()},
+               **{"g_" + k: v for k, v in grads.items()})
+    np.savez_compressed(os.path.join(HERE, "he2rna.npz"), **out)
+    print("he2rna: eval mean |.|", float(np.abs(pred_eval).mean()), "nan", bool(np.isnan(pred_eval).any()), "keys", sorted(sd))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats", "early_stop", "kfold", "pipeline"]
+    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats", "early_stop", "kfold", "pipeline", "he2rna"]
     if "vit_tiny" in which:
         gold_vit_tiny()
     if "vis_tiny" in which:
@@ -451,3 +483,5 @@ if __name__ == "__main__":
         gold_kfold()
     if "pipeline" in which:
         gold_pipeline()
+    if "he2rna" in which:
+        gold_he2rna()

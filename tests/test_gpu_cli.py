@@ -79,3 +79,7 @@ def test_pipeline_clis(tmp_path):
     assert os.path.basename(pdir).endswith("_g") and os.path.exists(os.path.join(pdir, "model_best.pt"))
     sd = torch.load(os.path.join(pdir, "model_best.pt"), map_location="cpu")
     assert sd["linear_head.1.weight"].shape == (24, 2048) and "transformer.layers.5.1.net.3.weight" in sd
+    # the MLP comparator through the same CLI (pretrain_gtex.py:102-105,118-120): whole model pickled as model.pt
+    hmodel, hdir = pretrain_gtex.main(["--path_csv", ref, "--feature_path", feat, "--save_dir", os.path.join(root, "pre"), "--exp_name", "h",
+                                       "--quick", "1", "--batch_size", "4", "--model", "he2rna"])
+    assert os.path.exists(os.path.join(hdir, "model.pt")) and hmodel.conv2.weight.shape == (24, 256, 1)
