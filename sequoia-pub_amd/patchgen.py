@@ -90,6 +90,7 @@ class ArraySlide:
     def __init__(self, levels, properties=None):
         self.levels = [np.asarray(a) for a in levels]
         self.level_dimensions = [(a.shape[1], a.shape[0]) for a in self.levels]       # (width, height) like OpenSlide
+        self.dimensions = self.level_dimensions[0]
         self.properties = dict(properties or {})
 
     def read_region(self, location, level, size):

@@ -127,3 +127,40 @@ def sliding_window_method(df, tile_features, model, inds_gene_of_interest, strid
         for gi, g in enumerate(genes):
             preds[g][index[t]] = sel[t, gi]
     return preds
+
+
+@torch.no_grad()
+def sliding_window_any_model(df, tile_features, model, inds_gene_of_interest, stride, model_type, batch_windows=256):
+    """visualize.py:35-102 for the comparator models (``model_type`` 'vit' or 'he2rna'; ViS takes the gather/vote path
+    above): window batches [w, 100, D] are built from the feature cache (zero padding, :72-75), HE2RNA gets them as
+    channels x tiles (:80-81), and the window predictions of the requested genes are combined per tile with the same
+    rule (stride 10: last writer; stride < 10: mean over the windows containing the tile, in visiting order)."""
+    genes = list(inds_gene_of_interest)
+    members, _ = enumerate_windows(df['xcoord_tf'].values, df['ycoord_tf'].values, stride)
+    index = list(df.index)
+    preds = {g: {} for g in genes}
+    if len(members) == 0 or not genes:
+        return preds
+    dev = next(model.parameters()).device
+    feats = tile_features.to(dev, torch.float32)
+    feats_pad = torch.cat([feats, torch.zeros(1, feats.shape[1], device=dev)])           # row -1 = the zero padding
+    mem = torch.from_numpy(members).to(dev)
+    gsel = torch.as_tensor(genes, device=dev)
+    win_pred = []
+    for s in range(0, mem.shape[0], batch_windows):
+        x = feats_pad[mem[s:s + batch_windows]]                                           # [w, 100, D]
+        if model_type == 'he2rna':
+            x = x.transpose(1, 2)
+        win_pred.append(model(x)[:, gsel].float())
+    win_pred = torch.cat(win_pred).cpu().numpy()                                          # [W, len(genes)]
+    per_tile = {}
+    for w, row in enumerate(members):
+        for t in row[row >= 0]:
+            if stride == 10:
+                per_tile[t] = [w]
+            else:
+                per_tile.setdefault(t, []).append(w)
+    for t, ws in per_tile.items():
+        for gi, g in enumerate(genes):
+            preds[g][index[t]] = win_pred[ws[0], gi] if stride == 10 else np.mean(win_pred[ws, gi])
+    return preds

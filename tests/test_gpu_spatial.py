@@ -95,3 +95,62 @@ def test_all_gene_vote_matches_literal_loop(stride):
     assert rel_err(out[covered], b) < 1e-4
     if stride < 10:
         assert votes.max() > 10                     # tiles in the interior belong to many windows
+
+
+def test_visualize_cli_on_a_synthetic_slide(tmp_path):
+    """spatial_vis/visualize.py:104-307 end to end: an in-memory 20x slide, mask -> valid tiles -> ResNet feature cache ->
+    two-fold ViS ensemble and one HE2RNA fold -> stride-1 CSV; the CSV equals the library calls on the same cache."""
+    import os
+    import pickle
+    from oracle import resnet_oracle
+    from sequoia_pub_amd.cli import visualize
+    from sequoia_pub_amd.he2rna import HE2RNA
+    from sequoia_pub_amd.resnet import resnet50
+    from sequoia_pub_amd.vis import ViS
+    _lib.require_gpu()
+    root = str(tmp_path)
+    rs = np.random.RandomState(4)
+    nx, ny, G = 9, 8, 24
+    arr = rs.randint(0, 256, ((ny + 1) * 256, (nx + 1) * 256, 3), dtype=np.uint8)         # [height, width, 3]
+    os.makedirs(os.path.join(root, "TCGA", "P"))
+    np.save(os.path.join(root, "TCGA", "P", "TCGA-X.npy"), arr)
+    mask = np.ones(((nx + 1) * 8, (ny + 1) * 8), dtype=bool)                                # slide width x height / 32, all tissue
+    mask[:, 56:] = False                                                                   # background from tile row 7 on
+    np.save(os.path.join(root, "mask.npy"), mask)
+    genes = [f"G{i}" for i in range(G)]
+    rw = os.path.join(root, "resnet.pth")
+    rn = resnet50()
+    torch.save({**rn.state_dict(), **resnet_oracle.init_resnet50_state_dict(seed=3)}, rw)
+    for mt in ("vis", "he2rna"):
+        ck = os.path.join(root, f"{mt}_resnet", "st")
+        os.makedirs(ck)
+        pickle.dump({"genes": genes}, open(os.path.join(ck, "test_results.pkl"), "wb"))
+        torch.manual_seed(7)
+        for fold in (0, 1):
+            if mt == "vis":
+                m = ViS(G, 2048, 6, 16, 64, 64, 64, device="cpu")
+                torch.save(m.state_dict(), os.path.join(ck, "model_best.pt" if fold == 0 else f"model_best_{fold}.pt"))
+            else:
+                m = HE2RNA(input_dim=2048, layers=[256, 256], ks=[1, 2, 5, 10, 20, 50, 100], output_dim=G)
+                torch.save(m, os.path.join(ck, f"model_{fold}.pt"))
+    common = ["--study", "st", "--project", "P", "--gene_names", "G3,G17,nope", "--wsi_file_name", "TCGA-X.npy", "--save_folder", "t",
+              "--feat_type", "resnet", "--slide_path", os.path.join(root, "TCGA", "P"), "--mask_path", os.path.join(root, "mask.npy"),
+              "--out_root", os.path.join(root, "vis_out"), "--extractor_weights", rw, "--compute_dtype", "fp32"]
+    res, path = visualize.main(common + ["--model_type", "vis", "--folds", "0,1", "--checkpoint", os.path.join(root, "vis_resnet", "st")])
+    assert os.path.basename(path) == "stride-1.csv" and len(res) == nx * (ny - 1)            # the background strip drops one tile row
+    assert {"xcoord", "ycoord", "xcoord_tf", "ycoord_tf", "G3_0", "G3_1", "G3", "G17"} <= set(res.columns) and "nope" not in res.columns
+    back = pd.read_csv(path, index_col=0)
+    np.testing.assert_allclose(back["G3"].values, res[["G3_0", "G3_1"]].mean(axis=1).values, rtol=1e-6)
+    # the same numbers from the library on the same feature cache
+    feat_model = resnet50()
+    feat_model.load_state_dict(torch.load(rw))
+    feat_model = feat_model.to("cuda:0").eval()
+    df = visualize.valid_tiles(mask, (arr.shape[1], arr.shape[0]), 256)
+    tiles = visualize.read_tiles(visualize.open_slide(os.path.join(root, "TCGA", "P", "TCGA-X.npy")), df, 256, 256)
+    cache = feat_model.extract_patches_u8(tiles.cuda())
+    m = ViS(G, 2048, 6, 16, 64, 64, 64, device="cuda:0")
+    m.load_state_dict(torch.load(os.path.join(root, "vis_resnet", "st", "model_best_1.pt")))
+    direct = sliding_window_method(df, cache, m.to("cuda:0").eval(), [3], 1)
+    np.testing.assert_allclose(res["G3_1"].values, np.array([direct[3][i] for i in res.index]), rtol=1e-5, atol=1e-6)
+    res_h, _ = visualize.main(common + ["--model_type", "he2rna", "--folds", "1", "--checkpoint", os.path.join(root, "he2rna_resnet", "st")])
+    assert np.isfinite(res_h["G17"].values).all() and np.array_equal(res_h["G17"].values, res_h["G17_1"].values)
