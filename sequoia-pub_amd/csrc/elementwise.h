@@ -7,9 +7,12 @@ int sq_k_add_pos(const float* x, const float* pos, float* X, bf16_t* Xh, int B, 
 // out[b,:] = mean_n X[b,n,:]       (tformer_lin.py:22 via s(mean x), :103); optional bf16 copy
 int sq_k_add_pos_gather(const float* src, const int32_t* idx, const float* pos, float* X, bf16_t* Xh, int B, int N, int D, hipStream_t s);
 int sq_k_token_mean(const float* X, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s);
+int sq_k_token_mean_any(const void* X, int in_dtype, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s);   // X fp32 or bf16
 // y = LayerNorm_D(x) * g + b       (rows of length D <= 4096, eps 1e-5); out f32 or bf16; optional mean/rstd save
 int sq_k_ln_rows(const float* x, const float* g, const float* b, void* y, int out_dtype, int R, int D,
                  float* mean_out, float* rstd_out, hipStream_t s);
+int sq_k_ln_rows_any(const void* x, int in_dtype, const float* g, const float* b, void* y, int out_dtype, int R, int D,
+                     float* mean_out, float* rstd_out, hipStream_t s);   // x fp32 or bf16
 // y = GELU(LayerNorm_64(x) * g + b) per 64-wide head group; x f32 [R, C] with C % 64 == 0, g/b [C]
 int sq_k_ln64_gelu(const float* x, const float* g, const float* b, void* y, int out_dtype, int R, int C, hipStream_t s);
 // dst = (T) src

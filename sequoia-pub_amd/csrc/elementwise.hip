@@ -31,8 +31,20 @@ __global__ void add_pos_gather_kernel(const float4* __restrict__ src, const int3
     }
 }
 
+// four consecutive elements of a row as floats: fp32 storage (16 bytes) or bf16 storage (8 bytes)
+template <bool IN_BF16>
+__device__ __forceinline__ float4 load4(const void* base, size_t i4) {
+    if constexpr (IN_BF16) {
+        const uint2 t = reinterpret_cast<const uint2*>(base)[i4];
+        return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+    } else {
+        return reinterpret_cast<const float4*>(base)[i4];
+    }
+}
+
 // thread = (b, d4, quarter of the tokens); quarters combined through LDS in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void token_mean_kernel(const float4* __restrict__ X, float4* __restrict__ out, uint2* __restrict__ outh,
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void token_mean_kernel(const void* __restrict__ X, float4* __restrict__ out, uint2* __restrict__ outh,
                                                          int B, int N, int D4) {
     __shared__ float4 red[4][64];
     const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -40,10 +52,10 @@ __global__ __launch_bounds__(256) void token_mean_kernel(const float4* __restric
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < B * D4) {
         const int b = i / D4, d = i - b * D4;
-        const float4* p = X + (size_t)b * N * D4 + d;
+        const size_t p = (size_t)b * N * D4 + d;
         const int per = (N + 3) / 4, lo = q * per, hi = min(N, lo + per);
         for (int n = lo; n < hi; ++n) {
-            const float4 v = p[(size_t)n * D4];
+            const float4 v = load4<IN_BF16>(X, p + (size_t)n * D4);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -62,21 +74,20 @@ __global__ __launch_bounds__(256) void token_mean_kernel(const float4* __restric
 }
 
 // one wave per row; row kept in registers between the mean and variance passes
-template <int MAXI>
-__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
+template <int MAXI, bool IN_BF16>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const void* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ b, void* __restrict__ y, int out_bf16,
                                                       int R, int D, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
     const int D4 = D >> 2;
-    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
     float4 v[MAXI];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
         const int c = i * 64 + lane;
-        v[i] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = c < D4 ? load4<IN_BF16>(x, (size_t)row * D4 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / (float)D;
@@ -247,22 +258,39 @@ int sq_k_add_pos_gather(const float* src, const int32_t* idx, const float* pos, 
 }
 
 int sq_k_token_mean(const float* X, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s) {
+    return sq_k_token_mean_any(X, SQ_F32, out, outh, B, N, D, s);
+}
+
+int sq_k_token_mean_any(const void* X, int in_dtype, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s) {
     SQ_REQUIRE(D % 4 == 0, "token_mean: D=%d must be a multiple of 4", D);
     const int total = B * (D / 4);
-    hipLaunchKernelGGL(token_mean_kernel, dim3((total + 63) / 64), dim3(256), 0, s, (const float4*)X, (float4*)out,
-                       (uint2*)outh, B, N, D / 4);
+    if (in_dtype == SQ_BF16)
+        hipLaunchKernelGGL(token_mean_kernel<true>, dim3((total + 63) / 64), dim3(256), 0, s, X, (float4*)out, (uint2*)outh, B, N, D / 4);
+    else
+        hipLaunchKernelGGL(token_mean_kernel<false>, dim3((total + 63) / 64), dim3(256), 0, s, X, (float4*)out, (uint2*)outh, B, N, D / 4);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
 
 int sq_k_ln_rows(const float* x, const float* g, const float* b, void* y, int out_dtype, int R, int D, float* mean_out,
                  float* rstd_out, hipStream_t s) {
+    return sq_k_ln_rows_any(x, SQ_F32, g, b, y, out_dtype, R, D, mean_out, rstd_out, s);
+}
+
+int sq_k_ln_rows_any(const void* x, int in_dtype, const float* g, const float* b, void* y, int out_dtype, int R, int D, float* mean_out,
+                     float* rstd_out, hipStream_t s) {
     SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows: D=%d must be a multiple of 4 and <= 4096", D);
     const dim3 grid((R + 3) / 4), block(256);
     const int ob = out_dtype == SQ_BF16;
-    if (D <= 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
-    else if (D <= 2048) hipLaunchKernelGGL(ln_rows_kernel<8>, grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
-    else hipLaunchKernelGGL(ln_rows_kernel<16>, grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+    if (in_dtype == SQ_BF16) {
+        if (D <= 1024) hipLaunchKernelGGL((ln_rows_kernel<4, true>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+        else if (D <= 2048) hipLaunchKernelGGL((ln_rows_kernel<8, true>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+        else hipLaunchKernelGGL((ln_rows_kernel<16, true>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+    } else {
+        if (D <= 1024) hipLaunchKernelGGL((ln_rows_kernel<4, false>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+        else if (D <= 2048) hipLaunchKernelGGL((ln_rows_kernel<8, false>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+        else hipLaunchKernelGGL((ln_rows_kernel<16, false>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
+    }
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }

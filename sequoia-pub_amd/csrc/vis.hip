@@ -158,6 +158,11 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
     } else {
         if (int e = sq_k_add_pos_gather(gather_src, gather_idx, Pf(lay.pos), w.Xin[0], lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
     }
+    // Inference in bf16 mode keeps the residual stream x in bf16 only (the operand copy IS the stream): the two residual
+    // products of a layer then read and write 2-byte rows instead of 4-byte rows plus a 2-byte copy, LayerNorm and the
+    // token mean read half the bytes -- about a third of a layer's HBM traffic.  The fp32 stream stays for training
+    // (save_for_backward), for fp32 mode, and on request (SQ_VIS_FP32_STREAM=1).
+    const bool stream16 = lp && !save && !sq_env_flag("SQ_VIS_FP32_STREAM");
     SqSideStream* fs = (lp && !sq_env_flag("SQ_FWD_ONE_STREAM")) ? sq_side_stream(1, 4 * SQ_MAX_DEPTH) : nullptr;
     hipStream_t s2 = fs ? fs->stream : st;
     int ev_next = 0;
@@ -177,7 +182,8 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             SQ_HIP_CHECK(hipEventRecord(ev, st));
             SQ_HIP_CHECK(hipStreamWaitEvent(s2, ev, 0));
         }
-        if (int e = sq_k_token_mean(Xin, w.Xbar32[s], lp ? (bf16_t*)w.Xbar[s] : nullptr, B, N, D, s2)) return e;
+        if (int e = sq_k_token_mean_any(stream16 ? Xin_t : (const void*)Xin, stream16 ? SQ_BF16 : SQ_F32, w.Xbar32[s],
+                                        lp ? (bf16_t*)w.Xbar[s] : nullptr, B, N, D, s2)) return e;
         if (lp && !sq_env_flag("SQ_FWD_NO_FUSED_SUMMARY")) {
             // Sm = Xbar Ws^T + bs;  Ts = GELU(LN64(Sm));  Cs = Ts_h Wc_h[:, 64:]^T + bc_h  -- one launch (summary.hip)
             if (int e = sq_launch_summary_fwd(w.Xbar[s], W(L.s_w), Pf(L.s_b), Pf(L.lns_g), Pf(L.lns_b), W(L.c_w), Pf(L.c_b), w.Sm[s],
@@ -223,9 +229,10 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             GemmArgs g; g.A = w.O[s]; g.lda = HD; g.a_bytes = (size_t)M * HD * es;
             g.B = W(L.proj_w); g.ldb = HD; g.b_bytes = Wrem(L.proj_w); g.bias = Pf(L.proj_b);
             g.res = Xin; g.ldres = D; g.C = w.X1[s]; g.ldc = D; g.M = M; g.N = D; g.K = HD;
+            if (stream16) { g.res = Xin_t; g.res_dtype = SQ_BF16; g.out_dtype = SQ_BF16; }     // X1 as bf16 in the same buffer
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
-        if (int e = sq_k_ln_rows(w.X1[s], Pf(L.ffln_g), Pf(L.ffln_b), w.Y[s], dtype, M, D, nullptr, nullptr, st)) return e;
+        if (int e = sq_k_ln_rows_any(w.X1[s], stream16 ? SQ_BF16 : SQ_F32, Pf(L.ffln_g), Pf(L.ffln_b), w.Y[s], dtype, M, D, nullptr, nullptr, st)) return e;
         {   // H1 = GELU(Y W1^T + b1)
             GemmArgs g; g.A = w.Y[s]; g.lda = D; g.a_bytes = (size_t)M * D * es;
             g.B = W(L.ff1_w); g.ldb = D; g.b_bytes = Wrem(L.ff1_w); g.bias = Pf(L.ff1_b);
@@ -239,11 +246,12 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             g.B = W(L.ff2_w); g.ldb = D; g.b_bytes = Wrem(L.ff2_w); g.bias = Pf(L.ff2_b);
             g.res = w.X1[s]; g.ldres = D; g.C = Xout; g.ldc = D;
             g.C2 = lp ? (bf16_t*)Xout_lp : nullptr; g.ldc2 = D; g.M = M; g.N = D; g.K = D;
+            if (stream16) { g.res_dtype = SQ_BF16; g.C = Xout_lp; g.out_dtype = SQ_BF16; g.C2 = nullptr; }
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
     }
     const float* Xfin = w.Xin[save ? c->depth : 0];
-    if (int e = sq_k_token_mean(Xfin, w.xm, nullptr, B, N, D, st)) return e;
+    if (int e = sq_k_token_mean_any(stream16 ? w.Xin_lp[0] : (const void*)Xfin, stream16 ? SQ_BF16 : SQ_F32, w.xm, nullptr, B, N, D, st)) return e;
     if (head_in)        // the caller applies the (linear) head itself, e.g. after averaging over windows: LN output in fp32
         return sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), head_in, SQ_F32, B, D, nullptr, nullptr, st);
     if (int e = sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), w.xn, dtype, B, D, nullptr, nullptr, st)) return e;
