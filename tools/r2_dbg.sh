@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for v in 0 1 2 4 3 7; do
+for v in 0 8; do
   SQ_TAIL_DBG=$v SQ_BENCH_KERNELS=gpurun_out/r2_dbg_k$v.json timeout 600 python bench.py --no-secondary --no-cpu-baseline --steps 6 > gpurun_out/r2_dbg_$v.log 2>&1
   python -c "
 import json; d=json.load(open('gpurun_out/r2_dbg_k$v.json'))
