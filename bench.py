@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 import sequoia_pub_amd  # noqa: E402,F401
 from sequoia_pub_amd import _lib, synth  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md); bf16x3: three bf16 MFMAs per product
 HBM_PEAK_GBS = 8000.0
 
 VIS_CFG = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16,
@@ -252,13 +252,14 @@ def workload_pipeline(args, rank, world, device):
                 if k.endswith("gamma"):
                     rn.flat[off:off + shape[0]] = 0.3
     else:
-        rn = resnet50(pretrained=False, compute_dtype=args.dtype).to(device).eval()
+        rn = resnet50(pretrained=False, compute_dtype=args.dtype).to(device).eval()      # bf16x3: split-bf16 embedder (parity-grade)
         for m in rn.modules():                 # non-trivial BN statistics so folding is exercised
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.running_mean.normal_(0, 0.1)
                 m.running_var.uniform_(0.5, 1.5)
     cfg = dict(VIS_CFG, input_dim=1024 if uni else 2048)
-    vis = ViS(**cfg, num_clusters=100, device=str(device), compute_dtype=args.dtype).to(device).eval()
+    vis_dtype = "fp32" if args.dtype == "bf16x3" else args.dtype      # the aggregator (0.2 % of the FLOP) stays exact fp32 in the split mode
+    vis = ViS(**cfg, num_clusters=100, device=str(device), compute_dtype=vis_dtype).to(device).eval()
     pipe = SlidePipeline(rn, vis, sub_batch=min(args.sub_batch, 256) if uni else args.sub_batch)
     # streaming form (default): the last slide's k-Means + ViS forward of a step run under the next step's first ResNet;
     # whatever is still in flight is flushed inside the timed region.  --no-stream: every step completes on its own.
@@ -518,7 +519,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: as many as make the timed region >= 2.5 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "pipeline"), choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--batch", type=int, default=64, help="slides per GPU per step (vis_* / train_kfold)")
     ap.add_argument("--epochs", type=int, default=2, help="train_kfold workload: epochs per fold")
     ap.add_argument("--slides", type=int, default=8, help="pipeline workload: slides per GPU per step")

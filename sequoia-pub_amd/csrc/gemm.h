@@ -35,6 +35,8 @@ struct GemmArgs {
     // implicit-GEMM convolution view of A: NHWC [n, H, W, Cin]; K = KH*KW*Cin, tap-major
     int conv = 0, H = 0, W = 0, Cin = 0, OH = 0, OW = 0, KW = 1, stride = 1, pad = 0;
     size_t a_bytes = 0, b_bytes = 0;   // extents of A and B for the buffer descriptors (< 2 GiB)
+    // SQ_BF16X3 only: A / B / res / C point at the hi plane; the lo plane lies this many ELEMENTS behind it
+    long long plA = 0, plB = 0, plRes = 0, plC = 0;
     // split-K: set splitk_ws (fp32 scratch) to allow it; the launcher picks the slice count
     float* splitk_ws = nullptr;
     size_t splitk_ws_bytes = 0;
@@ -45,6 +47,8 @@ struct GemmArgs {
 
 // dtype: SQ_F32 (v_mfma_f32_32x32x2_f32, exact fp32) or SQ_BF16 (v_mfma_f32_32x32x16_bf16)
 int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream);
+// split-bf16 product (gemm_x3.hip): hi/lo bf16 planes, three bf16 MFMAs per product, fp32 accumulation; bias / residual / ReLU only
+int sq_launch_gemm_x3(const GemmArgs& a, hipStream_t stream);
 // TN product for weight gradients:  C[M,N] = alpha * sum_k A[k, M-index] * B[k, N-index]
 //   A [K, M] (lda) and B [K, N] (ldb) are row-major with the CONTRACTION index as the row, i.e. the
 //   activations exactly as the forward pass stored them (no transposed copies).  a.M / a.N = extents of C,

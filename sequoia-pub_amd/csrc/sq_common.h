@@ -12,6 +12,7 @@
 
 #define SQ_F32 0
 #define SQ_BF16 1
+#define SQ_BF16X3 2   // split bf16: every fp32 value as hi + lo bf16 planes, three MFMAs per product (gemm_x3.hip)
 
 void sq_set_error(const char* fmt, ...);
 bool sq_prof_on();
@@ -135,4 +136,4 @@ template <> struct sq_type<float> { static constexpr int id = SQ_F32; };
 template <> struct sq_type<bf16_t> { static constexpr int id = SQ_BF16; };
 
 static inline size_t sq_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-static inline int sq_dtype_size(int dtype) { return dtype == SQ_BF16 ? 2 : 4; }
+static inline int sq_dtype_size(int dtype) { return dtype == SQ_BF16 ? 2 : 4; }   // SQ_BF16X3: two 2-byte planes = 4

@@ -106,6 +106,9 @@ class ResNet50(nn.Module):
         w = w.to(dev)
         if self.compute_dtype == _lib.SQ_BF16:
             w = w.to(torch.bfloat16)
+        elif self.compute_dtype == _lib.SQ_BF16X3:      # hi plane, then lo plane: w ~= hi + lo to 2^-17
+            hi = w.to(torch.bfloat16)
+            w = torch.cat([hi, (w - hi.float()).to(torch.bfloat16)])
         self._packed = (key, w, b.to(dev))
         return self._packed[1], self._packed[2]
 
