@@ -3,10 +3,13 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload pipeline|vis_train|vis_fwd|train_kfold|spatial] [--dtype bf16|fp32]
 
-Default workload = the headline configuration of BASELINE.json's metric (config 3): 1000 x 224 x 224 uint8
-patches per slide -> ResNet-50 embed -> k-Means(100) -> ViS forward, bf16, patches resident in HBM when the timed
-region starts.  The same JSON line carries ``secondary``: the PCIe-inclusive twin (patches uploaded from pinned host
-memory every step), BASELINE config 2 (``vis_train``) and the fp32 parity-mode pipeline, each timed the same way.
+Default workload = the headline configuration of BASELINE.json's metric (config 3) AS STATED: 1000 x 224 x 224 uint8
+patches per slide, streamed from pinned host memory every step -> ResNet-50 embed -> k-Means(100) -> ViS forward, in the
+parity-grade mode (``f16x3``: fp16 hi/lo planes, three MFMAs per product, fp32 accumulation -- the reference's fp32
+results to ~1e-6, cluster labels bit-equal).  The line carries ``accuracy_vs_reference`` (the golden slide of
+tests/golden/pipeline_slide.npz through the same pipeline in the same mode) and ``secondary``: the resident twin (upload
+outside the timed region), the plain-bf16 throughput mode with ITS accuracy figures, the exact-fp32 mode, BASELINE
+config 2 (``vis_train``), the UNI embedder and config 5, each timed the same way in a fresh process.
 
 One process per GPU: with --gpus N > 1 and no WORLD_SIZE in the environment bench.py starts the N ranks itself
 (torch.distributed.run); slides are independent units, so ranks shard them with no data-path collective.  Only the
@@ -34,7 +37,7 @@ sys.path.insert(0, ROOT)
 import sequoia_pub_amd  # noqa: E402,F401
 from sequoia_pub_amd import _lib, synth  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md); bf16x3: three bf16 MFMAs per product
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "f16x3": 2500.0 / 3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md); bf16x3: three bf16 MFMAs per product
 HBM_PEAK_GBS = 8000.0
 
 VIS_CFG = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16,
@@ -258,7 +261,7 @@ def workload_pipeline(args, rank, world, device):
                 m.running_mean.normal_(0, 0.1)
                 m.running_var.uniform_(0.5, 1.5)
     cfg = dict(VIS_CFG, input_dim=1024 if uni else 2048)
-    vis_dtype = "fp32" if args.dtype == "bf16x3" else args.dtype      # the aggregator (0.2 % of the FLOP) stays exact fp32 in the split mode
+    vis_dtype = "fp32" if args.dtype in ("bf16x3", "f16x3") else args.dtype      # the aggregator (0.2 % of the FLOP) stays exact fp32 in the split mode
     vis = ViS(**cfg, num_clusters=100, device=str(device), compute_dtype=vis_dtype).to(device).eval()
     pipe = SlidePipeline(rn, vis, sub_batch=min(args.sub_batch, 256) if uni else args.sub_batch)
     # streaming form (default): the last slide's k-Means + ViS forward of a step run under the next step's first ResNet;
@@ -266,8 +269,8 @@ def workload_pipeline(args, rank, world, device):
     run = pipe if args.no_stream else pipe.submit
     host = [torch.from_numpy(synth.patches_u8(rank * nslides + i, npatch, 224)) for i in range(nslides)]
     if args.from_host:
-        # PCIe-inclusive variant (reported in DESIGN.md, never `value` of the default run): slides live in pinned host
-        # memory; each step uploads them on a copy stream, slide i+1's upload under slide i's embedding
+        # BASELINE config 3 as stated (the default): slides live in pinned host memory; each step uploads them on a
+        # copy stream, slide i+1's upload under slide i's embedding
         host = [h.pin_memory() for h in host]
         copy_stream = torch.cuda.Stream(device=device)
         staging = [torch.empty_like(h, device=device) for h in host]
@@ -432,6 +435,50 @@ def workload_train_kfold(args, rank, world, device):
                         "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient, bucketed under the backward pass)" if world > 1 else "")})
 
 
+def accuracy_vs_reference(dtype_name, device):
+    """Checker leg (rank 0, N = 1, outside every timed region): the 1000-patch slide of tests/golden/pipeline_slide.npz
+    -- made by the REFERENCE's resnet50 + scikit-learn KMeans + ViS (tests/golden/make_golden.py gold_pipeline) -- through
+    SlidePipeline in the mode the line is quoted in.  What a reader needs to price the throughput number: feature error,
+    how many of the 1000 cluster labels equal scikit-learn's, partition agreement, 20 820-gene prediction error.
+    oracle/ supplies only the seeded weight recipes of the golden (no arithmetic of the path)."""
+    from oracle import resnet_oracle as ro, vis_oracle
+    from sequoia_pub_amd.pipeline import SlidePipeline
+    from sequoia_pub_amd.resnet import resnet50
+    from sequoia_pub_amd.vis import ViS
+    path = os.path.join(ROOT, "tests", "golden", "pipeline_slide.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    cfg = dict(VIS_CFG, input_dim=2048)
+    rn = resnet50(pretrained=False, compute_dtype=dtype_name)
+    full = rn.state_dict()
+    full.update(ro.init_resnet50_state_dict(seed=99, perturb_bn=True))
+    rn.load_state_dict(full)
+    vis = ViS(**cfg, device=str(device), compute_dtype="fp32" if dtype_name in ("bf16x3", "f16x3") else dtype_name)
+    vis.load_state_dict(vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=31), seed=32))
+    pipe = SlidePipeline(rn.to(device).eval(), vis.to(device).eval(), n_clusters=100, sub_batch=250)
+    out = pipe([torch.from_numpy(synth.patches_u8(7, 1000, 224)).to(device)])
+    torch.cuda.synchronize()
+    feats = out["features"][0].cpu().numpy()
+    labels = out["labels"][0].cpu().numpy().astype(np.int64)
+    pred = out["pred"][0].cpu().numpy().astype(np.float64)
+    ref_l = z["labels"].astype(np.int64)
+
+    def rel(a, b):
+        return float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())
+    cont = np.zeros((100, 100), dtype=np.int64)
+    np.add.at(cont, (labels, ref_l), 1)
+    comb = lambda x: int((x * (x - 1) // 2).sum())
+    total = 1000 * 999 // 2
+    rand = (total + 2 * comb(cont) - comb(cont.sum(1)) - comb(cont.sum(0))) / total
+    return {"golden": "tests/golden/pipeline_slide.npz (reference resnet50 + scikit-learn KMeans(100, random_state=0) + ViS, fp32 CPU)",
+            "mode": dtype_name,
+            "feature_rel_err": float(f"{rel(feats[::64], z['feat_probe'].astype(np.float64)):.3e}"),
+            "labels_equal": int((labels == ref_l).sum()), "labels_total": 1000,
+            "partition_rand_index": round(float(rand), 6),
+            "prediction_rel_err": float(f"{rel(pred, z['pred'].astype(np.float64)):.3e}")}
+
+
 WORKLOADS = {"vis_fwd": workload_vis_fwd, "vis_train": workload_vis_train, "pipeline": workload_pipeline, "spatial": workload_spatial,
              "train_kfold": workload_train_kfold}
 
@@ -519,7 +566,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: as many as make the timed region >= 2.5 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("SQ_BENCH_WORKLOAD", "pipeline"), choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "bf16x3", "f16x3"],
+                    help="default: f16x3 (parity-grade split fp16) for the pipeline with the ResNet-50 embedder, bf16 otherwise")
     ap.add_argument("--batch", type=int, default=64, help="slides per GPU per step (vis_* / train_kfold)")
     ap.add_argument("--epochs", type=int, default=2, help="train_kfold workload: epochs per fold")
     ap.add_argument("--slides", type=int, default=8, help="pipeline workload: slides per GPU per step")
@@ -529,10 +577,17 @@ def main():
     ap.add_argument("--batch-windows", type=int, default=1024, help="spatial workload: windows per ViS forward")
     ap.add_argument("--embedder", default="resnet", choices=["resnet", "uni"], help="pipeline workload: patch embedder")
     ap.add_argument("--no-stream", action="store_true", help="pipeline workload: finish every step's slides before the next step starts")
-    ap.add_argument("--from-host", action="store_true", help="pipeline workload: upload the patches from pinned host memory every step")
+    ap.add_argument("--resident", action="store_true", help="pipeline workload: patches already in HBM when the timed region starts "
+                    "(default: uploaded from pinned host memory every step, as BASELINE config 3 states)")
+    ap.add_argument("--no-accuracy", action="store_true", help="pipeline workload: skip the accuracy_vs_reference checker leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the secondary measurements")
     args = ap.parse_args()
+    args.from_host = not args.resident
+    if args.dtype is None:
+        args.dtype = "f16x3" if (args.workload == "pipeline" and args.embedder == "resnet") else "bf16"
+    if args.dtype in ("bf16x3", "f16x3") and not (args.workload == "pipeline" and args.embedder == "resnet"):
+        raise SystemExit(f"--dtype {args.dtype} is the split mode of the ResNet-50 embedder (pipeline workload)")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
@@ -562,18 +617,26 @@ def main():
     line = {"metric": METRIC, "value": res["value"], "unit": "slides/s", "n_gpus": world, "steps": res["steps"],
             "warmup": res["warmup"], "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": res["config"],
-            "roofline": res.get("roofline"), "cpu_baseline": res.get("cpu_baseline"), "timed_region_s": res["timed_region_s"]}
+            "roofline": res.get("roofline"), "cpu_baseline": res.get("cpu_baseline"), "timed_region_s": res["timed_region_s"],
+            "ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "backend": (torch.distributed.get_backend() if world > 1 else None)}
+    if args.workload == "pipeline" and args.embedder == "resnet" and rank == 0 and world == 1 and not args.no_accuracy:
+        try:
+            line["accuracy_vs_reference"] = accuracy_vs_reference(args.dtype, device)
+        except Exception as e:                          # the checker leg must not cost the line
+            line["accuracy_vs_reference"] = {"error": f"{type(e).__name__}: {e}"}
 
     # secondary measurements of the default run (N = 1): the PCIe-inclusive twin, BASELINE config 2, the fp32 parity
     # mode.  Each runs in a fresh process (same script, same timing rules): a process that has already created one
     # workload's helper streams maps later streams onto the same few hardware queues, which serialises what the
     # next workload wants to overlap (measured: from-host 41 instead of 53 slides/s, vis_train 10.5 instead of 3.6 ms).
-    if args.workload == "pipeline" and args.dtype == "bf16" and not args.from_host and world == 1 and not args.no_secondary:
+    if args.workload == "pipeline" and args.dtype == "f16x3" and args.from_host and args.embedder == "resnet" and world == 1 and not args.no_secondary:
         import subprocess
         sec = {}
-        for key, extra in (("pipeline_from_pinned_host", ["--workload", "pipeline", "--from-host"]),
+        for key, extra in (("pipeline_resident_in_hbm", ["--workload", "pipeline", "--resident", "--no-accuracy"]),
+                           ("pipeline_bf16_throughput_mode_from_pinned_host", ["--workload", "pipeline", "--dtype", "bf16"]),
+                           ("pipeline_fp32_exact_mfma_mode", ["--workload", "pipeline", "--dtype", "fp32", "--slides", "2", "--sub-batch", "250", "--no-accuracy"]),
                            ("vis_train_bf16", ["--workload", "vis_train"]),
-                           ("pipeline_fp32_parity_mode", ["--workload", "pipeline", "--dtype", "fp32", "--slides", "2", "--sub-batch", "250"]),
                            ("pipeline_uni_vit_l16_embedder", ["--workload", "pipeline", "--embedder", "uni", "--slides", "2"]),
                            ("spatial_50k_tiles", ["--workload", "spatial"])):
             cmd = [sys.executable, os.path.abspath(__file__), "--no-secondary", "--no-cpu-baseline", "--warmup", str(args.warmup)] + extra
@@ -583,7 +646,8 @@ def main():
                 if r.returncode != 0 or not last:
                     raise RuntimeError((r.stderr or r.stdout)[-400:])
                 d = json.loads(last[-1])
-                sec[key] = {k: d[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "config", "roofline")}
+                sec[key] = {k: d[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "config", "roofline",
+                                              "accuracy_vs_reference") if k in d}
             except Exception as e:                      # a secondary failure must not cost the headline line
                 sec[key] = {"error": f"{type(e).__name__}: {e}"}
         line["secondary"] = sec

@@ -27,7 +27,9 @@ typedef void* sq_event_t;  /* hipEvent_t */
 #define SQ_DTYPE_F32 0  /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
 #define SQ_DTYPE_BF16 1 /* bf16 MFMA, fp32 accumulate: perf mode              */
 #define SQ_DTYPE_BF16X3 2 /* split bf16 (sq_resnet50_extract only): every fp32 value as hi + lo bf16 planes, a.b = a_hi.b_hi + a_hi.b_lo +
-                             a_lo.b_hi on bf16 MFMAs with fp32 accumulation -- ~2^-17 per operand, the fast parity-grade mode */
+                             a_lo.b_hi on bf16 MFMAs with fp32 accumulation -- 2^-18 per operand, fp32's exponent range */
+#define SQ_DTYPE_F16X3 3  /* the same with fp16 planes: 22 significant bits (fp32-class results), values must stay below 65504
+                             (an overflow propagates to the features as inf / NaN); the fast parity mode */
 
 #define SQ_MAX_DEPTH 16
 #define SQ_HEAD_DIM 64 /* dimensions_f = dimensions_s = dimensions_c = 64 (src/main.py:147,167,202) */
@@ -215,8 +217,10 @@ int sq_kmeans_fit(const float* X, int n_slides, int n_samples, int dim, int n_cl
  * [cout][kh][kw][cin] (conv 0: K = 147 zero-padded to k_padded = 152) with eval-mode BatchNorm
  * folded in, bias (fp32) at b_off.  Conv order: conv1; then per bottleneck conv1, conv2, conv3,
  * [downsample.0 for the first block of each layer].
- * dtype SQ_DTYPE_BF16X3: `weights` = the bf16 hi plane [w_total] followed by the bf16 lo plane [w_total]
- * (hi = bf16(w), lo = bf16(w - hi)) of the same packed fp32 weights.
+ * dtype SQ_DTYPE_BF16X3 / SQ_DTYPE_F16X3: `weights` = the 16-bit hi plane [w_total] followed by the lo plane [w_total]
+ * (hi = cvt(w'), lo = cvt(w' - hi)) of the packed fp32 weights w' = w * s[cout], and `bias` = [b_total] biases followed by
+ * [b_total] per-output-channel factors 1 / s (at the same b_off): s = 1 for bf16 planes; for fp16 planes a power of two
+ * that lifts each weight row to max |w'| in [256, 512) so that the lo plane stays in fp16's normal range.
  * sq_resnet50_extract: give EITHER patches_u8 (uint8 NHWC [n, S, S, 3]: /255 and ImageNet
  * normalisation fused) OR patches_f32_nchw (fp32 [n, 3, S, S], already normalised: the tensor the
  * reference feeds forward_extract).  features: f32 [n, 2048].  S in {224, 256, ...}, multiple of 32.
@@ -256,10 +260,11 @@ int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const f
  * bf16 lo plane (bf16(v - hi)) of the same shape;  C = act(A . W^T + bias + residual) with
  * a.w = a_hi.w_hi + a_hi.w_lo + a_lo.w_hi on bf16 MFMAs, fp32 accumulation.  Output: hi / lo planes (C_hi, C_lo) or
  * fp32 (C_f32) -- give exactly one.  act: 0 none, 2 ReLU.  K, N, lda, ldw, ldc, ldres multiples of 8; planes 16-byte
- * aligned and a multiple of 16 bytes apart.  conv_geom: NULL for a plain [M,K] A, or
+ * aligned and a multiple of 16 bytes apart.  fmt: 0 = bf16 planes, 1 = fp16 planes.  colscale (optional, [N] f32): factor on
+ * the accumulator column before the bias (undoes a power-of-two pre-scaling of the weight rows).  conv_geom: NULL for a plain [M,K] A, or
  * {n_img, H, W, Cin, OH, OW, KW, stride, pad} for an implicit-GEMM view of an NHWC activation (K = KH*KW*Cin, Cin % 32 == 0). */
-int sq_linear_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int ldw, const float* bias,
-                 const void* res_hi, const void* res_lo, int ldres, int act, void* C_hi, void* C_lo, float* C_f32, int ldc,
+int sq_linear_x3(int fmt, const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int ldw, const float* bias,
+                 const float* colscale, const void* res_hi, const void* res_lo, int ldres, int act, void* C_hi, void* C_lo, float* C_f32, int ldc,
                  int M, int N, int K, const int* conv_geom, sq_stream_t stream);
 
 /* Weight gradient of a linear layer: dW[N_out, N_in] (f32, lddw) = dY[T, N_out]^T . X[T, N_in], contracting

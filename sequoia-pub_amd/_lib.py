@@ -15,12 +15,14 @@ LIB_PATH = os.path.join(_HERE, "libsequoia_hip.so")
 SQ_F32 = 0
 SQ_BF16 = 1
 SQ_BF16X3 = 2       # split bf16 (hi + lo planes, three MFMAs per product): ResNet-50 embedder only
+SQ_F16X3 = 3        # the same with fp16 planes (22 significant bits, range 65504): the fast parity mode
 SQ_MAX_DEPTH = 16
 HEAD_DIM = 64
 
 DTYPES = {"fp32": SQ_F32, "f32": SQ_F32, "float32": SQ_F32, SQ_F32: SQ_F32,
           "bf16": SQ_BF16, "bfloat16": SQ_BF16, SQ_BF16: SQ_BF16,
-          "bf16x3": SQ_BF16X3, "split-bf16": SQ_BF16X3, SQ_BF16X3: SQ_BF16X3}
+          "bf16x3": SQ_BF16X3, "split-bf16": SQ_BF16X3, SQ_BF16X3: SQ_BF16X3,
+          "f16x3": SQ_F16X3, "fp16x3": SQ_F16X3, "split-fp16": SQ_F16X3, SQ_F16X3: SQ_F16X3}
 
 
 class VisConfig(ctypes.Structure):
@@ -148,7 +150,7 @@ def _declare(lib):
     lib.sq_linear_weight_grad.restype = i32
     lib.sq_linear_weight_grad.argtypes = [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, sz, vp]
     lib.sq_linear_x3.restype = i32
-    lib.sq_linear_x3.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.sq_linear_x3.argtypes = [i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.sq_cast_f32_to_bf16.restype = i32
     lib.sq_cast_f32_to_bf16.argtypes = [vp, vp, sz, vp]
     for name, (res, args) in _OPTIONAL.items():

@@ -37,6 +37,8 @@ struct GemmArgs {
     size_t a_bytes = 0, b_bytes = 0;   // extents of A and B for the buffer descriptors (< 2 GiB)
     // SQ_BF16X3 only: A / B / res / C point at the hi plane; the lo plane lies this many ELEMENTS behind it
     long long plA = 0, plB = 0, plRes = 0, plC = 0;
+    int x3_f16 = 0;                    // planes are fp16 (SQ_F16X3) instead of bf16
+    const float* colscale = nullptr;   // [N] per-column factor on the accumulator (undoes power-of-two pre-scaled weight rows)
     // split-K: set splitk_ws (fp32 scratch) to allow it; the launcher picks the slice count
     float* splitk_ws = nullptr;
     size_t splitk_ws_bytes = 0;

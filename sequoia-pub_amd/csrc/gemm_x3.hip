@@ -17,6 +17,7 @@
 // once), which is what the load-path-bound shapes of this network want.
 // Epilogue: acc -> LDS (fp32 tile) -> bias + residual (hi + lo) + ReLU -> split -> two 16-byte stores per 8 columns.
 #include "gemm.h"
+#include "x3_fmt.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -45,15 +46,10 @@ template <int WTN> struct X3Cfg {
     static constexpr int LOADS = 4 + (WTN == 1 ? 1 : 2);               // LDS-DMA instructions per thread per stage
 };
 
-__device__ __forceinline__ void mfma_bf16(const u32x4& a, const u32x4& b, f32x16& acc) {
-    union { u32x4 u; bf16x8 h; } ua, ub;
-    ua.u = a; ub.u = b;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.h, ub.h, acc, 0, 0, 0);
-}
-
-template <int WTN, bool CONV>
+template <int WTN, bool CONV, bool F16>
 __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
     using Cfg = X3Cfg<WTN>;
+    using Fmt = X3Fmt<F16>;
     constexpr int BN = Cfg::BN, B_BYTES = Cfg::B_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES, NSTAGE = Cfg::NSTAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -159,14 +155,20 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
     const int e_c8 = tid % BN8, e_rbase = tid / BN8;
     const int e_n = n0 + e_c8 * 8;
     const bool e_live = e_n < p.N;            // N % 8 == 0 (launcher)
-    float bias8[8];
+    float bias8[8], scale8[8];                // per-column scale: undoes the power-of-two pre-scaling of the weight rows (fp16 planes)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; scale8[e] = p.alpha; }
     if (e_live && p.bias) {
         const float* bsrc = p.bias + e_n;
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(bsrc), t1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = t0[e]; bias8[4 + e] = t1[e]; }
+    }
+    if (e_live && p.colscale) {
+        const float* ssrc = p.colscale + e_n;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(ssrc), t1 = *reinterpret_cast<const f32x4*>(ssrc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { scale8[e] = p.alpha * t0[e]; scale8[4 + e] = p.alpha * t1[e]; }
     }
 
     f32x16 acc[WTM][WTN];
@@ -213,15 +215,15 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j) mfma_bf16(al[s][i], bh[s][j], acc[i][j]);
+                for (int j = 0; j < WTN; ++j) Fmt::mma(al[s][i], bh[s][j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j) mfma_bf16(ah[s][i], bl[s][j], acc[i][j]);
+                for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bl[s][j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j) mfma_bf16(ah[s][i], bh[s][j], acc[i][j]);
+                for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bh[s][j], acc[i][j]);
         }
     };
 
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
     if (!e_live) return;
 
     const bf16_t* resh = p.res ? reinterpret_cast<const bf16_t*>(p.res) : nullptr;
-    bf16_t* ch = p.out_dtype == SQ_BF16X3 ? reinterpret_cast<bf16_t*>(p.C) : nullptr;
+    bf16_t* ch = p.out_dtype != SQ_F32 ? reinterpret_cast<bf16_t*>(p.C) : nullptr;
     float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) : nullptr;
     constexpr int U = 4;
 #pragma unroll
@@ -285,14 +287,12 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8 + 4);
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = p.alpha * v[e] + bias8[e];
+            for (int e = 0; e < 8; ++e) v[e] = scale8[e] * v[e] + bias8[e];
             if (resh) {
-                // identity = hi + lo (exact in fp32: both planes are multiples of one ulp of the value they split)
+                float idn[8];
+                x3_join8<F16>(rh[u], rl[u], idn);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += __uint_as_float(rh[u][e] << 16) + __uint_as_float(rl[u][e] << 16);
-                    v[2 * e + 1] += __uint_as_float(rh[u][e] & 0xffff0000u) + __uint_as_float(rl[u][e] & 0xffff0000u);
-                }
+                for (int e = 0; e < 8; ++e) v[e] += idn[e];
             }
             if (p.act == SQ_ACT_RELU) {
 #pragma unroll
@@ -305,11 +305,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
             }
             if (ch) {
                 u32x4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-                    lo[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
-                }
+                x3_split8<F16>(v, hi, lo);
                 *reinterpret_cast<u32x4*>(ch + (long long)m * p.ldc + e_n) = hi;
                 *reinterpret_cast<u32x4*>(ch + p.plC + (long long)m * p.ldc + e_n) = lo;
             }
@@ -317,19 +313,19 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
     }
 }
 
-template <int WTN>
+template <int WTN, bool F16>
 int launch_x3(const GemmArgs& a, hipStream_t stream) {
     using Cfg = X3Cfg<WTN>;
     static bool attr = false;
     if (!attr) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<WTN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<WTN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<WTN, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<WTN, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr = true;
     }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + Cfg::BN - 1) / Cfg::BN);
     const dim3 grid(tiles), block(512);
-    if (a.conv) hipLaunchKernelGGL((gemm_x3_kernel<WTN, true>), grid, block, Cfg::LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL((gemm_x3_kernel<WTN, false>), grid, block, Cfg::LDS_BYTES, stream, a);
+    if (a.conv) hipLaunchKernelGGL((gemm_x3_kernel<WTN, true, F16>), grid, block, Cfg::LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((gemm_x3_kernel<WTN, false, F16>), grid, block, Cfg::LDS_BYTES, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
@@ -345,12 +341,12 @@ int sq_launch_gemm_x3(const GemmArgs& a, hipStream_t stream) {
     SQ_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_x3: A/B/C must be 16-byte aligned");
     SQ_REQUIRE(a.a_bytes > 0 && a.a_bytes < (1ull << 31) && a.b_bytes > 0 && a.b_bytes < (1ull << 31),
                "gemm_x3: operand plane extents must be in (0, 2 GiB): %zu %zu", a.a_bytes, a.b_bytes);
-    SQ_REQUIRE(a.out_dtype == SQ_F32 || (a.out_dtype == SQ_BF16X3 && a.plC != 0 && (a.plC & 7) == 0), "gemm_x3: output is fp32 or hi/lo planes (plC)");
-    SQ_REQUIRE(a.ldc % 8 == 0 && (!a.res || (a.res_dtype == SQ_BF16X3 && a.ldres % 8 == 0 && a.plRes != 0 && (a.plRes & 7) == 0 && ((uintptr_t)a.res & 15) == 0)),
+    SQ_REQUIRE(a.out_dtype == SQ_F32 || ((a.out_dtype == SQ_BF16X3 || a.out_dtype == SQ_F16X3) && a.plC != 0 && (a.plC & 7) == 0), "gemm_x3: output is fp32 or hi/lo planes (plC)");
+    SQ_REQUIRE(a.ldc % 8 == 0 && (!a.res || ((a.res_dtype == SQ_BF16X3 || a.res_dtype == SQ_F16X3) && a.ldres % 8 == 0 && a.plRes != 0 && (a.plRes & 7) == 0 && ((uintptr_t)a.res & 15) == 0)),
                "gemm_x3: ldc / residual planes must allow 16-byte accesses");
     SQ_REQUIRE(!a.rowbias && !a.Cpre && !a.gelu_grad_of && !a.ln64_g && !a.C2 && (a.act == SQ_ACT_NONE || a.act == SQ_ACT_RELU),
                "gemm_x3: only bias / residual / ReLU epilogues");
-    SQ_REQUIRE(!a.bias || ((uintptr_t)a.bias & 15) == 0, "gemm_x3: bias must be 16-byte aligned");
+    SQ_REQUIRE((!a.bias || ((uintptr_t)a.bias & 15) == 0) && (!a.colscale || ((uintptr_t)a.colscale & 15) == 0), "gemm_x3: bias / colscale must be 16-byte aligned");
     if (a.conv) SQ_REQUIRE(a.Cin % BK == 0, "conv_x3: Cin=%d must be a multiple of the K-tile (%d)", a.Cin, BK);
     else SQ_REQUIRE(a.lda % 8 == 0, "gemm_x3: lda=%d must be a multiple of 8", a.lda);
     int prof = -1;
@@ -359,21 +355,26 @@ int sq_launch_gemm_x3(const GemmArgs& a, hipStream_t stream) {
         const double a_elems = a.conv ? (double)a.M / (a.OH * a.OW) * a.H * a.W * a.Cin : (double)a.M * a.K;
         const double bytes = (a_elems + (double)a.N * a.K) * 4.0 + (double)a.M * a.N * (4.0 + (a.res ? 4.0 : 0.0));
         char name[96];
-        snprintf(name, sizeof(name), "%s_bf16x3_M%d_N%d_K%d", a.conv ? "conv" : "gemm", a.M, a.N, a.K);
+        snprintf(name, sizeof(name), "%s_%s_M%d_N%d_K%d", a.conv ? "conv" : "gemm", a.x3_f16 ? "f16x3" : "bf16x3", a.M, a.N, a.K);
         prof = sq_prof_begin(name, flops, bytes, stream);
     }
-    const int rc = a.N % 128 == 0 ? launch_x3<2>(a, stream) : launch_x3<1>(a, stream);
+    int rc;
+    if (a.x3_f16) rc = a.N % 128 == 0 ? launch_x3<2, true>(a, stream) : launch_x3<1, true>(a, stream);
+    else rc = a.N % 128 == 0 ? launch_x3<2, false>(a, stream) : launch_x3<1, false>(a, stream);
     if (prof >= 0) sq_prof_end(prof, stream);
     return rc;
 }
 
 // C-ABI entry (include/sequoia_hip.h): one split-bf16 linear layer / convolution on caller-owned hi / lo planes
-extern "C" int sq_linear_x3(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int ldw, const float* bias,
-                            const void* res_hi, const void* res_lo, int ldres, int act, void* C_hi, void* C_lo, float* C_f32, int ldc,
+extern "C" int sq_linear_x3(int fmt, const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int ldw, const float* bias,
+                            const float* colscale, const void* res_hi, const void* res_lo, int ldres, int act, void* C_hi, void* C_lo, float* C_f32, int ldc,
                             int M, int N, int K, const int* conv_geom, void* stream) {
     SQ_REQUIRE(A_hi && A_lo && W_hi && W_lo && ((C_hi && C_lo) != (C_f32 != nullptr)), "linear_x3: null pointer (give C_hi + C_lo or C_f32)");
     SQ_REQUIRE((res_hi == nullptr) == (res_lo == nullptr), "linear_x3: residual needs both planes");
+    SQ_REQUIRE(fmt == 0 || fmt == 1, "linear_x3: fmt %d (0 = bf16 planes, 1 = fp16 planes)", fmt);
     GemmArgs g;
+    g.x3_f16 = fmt; g.colscale = colscale;
+    const int xdt = fmt ? SQ_F16X3 : SQ_BF16X3;
     g.M = M; g.N = N; g.K = K;
     g.A = A_hi; g.plA = (const bf16_t*)A_lo - (const bf16_t*)A_hi; g.lda = lda;
     g.B = W_hi; g.plB = (const bf16_t*)W_lo - (const bf16_t*)W_hi; g.ldb = ldw;
@@ -387,9 +388,9 @@ extern "C" int sq_linear_x3(const void* A_hi, const void* A_lo, int lda, const v
         g.a_bytes = ((size_t)(M - 1) * lda + K) * 2;
     }
     g.bias = bias; g.act = act;
-    if (res_hi) { g.res = res_hi; g.plRes = (const bf16_t*)res_lo - (const bf16_t*)res_hi; g.ldres = ldres; g.res_dtype = SQ_BF16X3; }
+    if (res_hi) { g.res = res_hi; g.plRes = (const bf16_t*)res_lo - (const bf16_t*)res_hi; g.ldres = ldres; g.res_dtype = xdt; }
     if (C_f32) { g.C = C_f32; g.out_dtype = SQ_F32; }
-    else { g.C = C_hi; g.plC = (bf16_t*)C_lo - (bf16_t*)C_hi; g.out_dtype = SQ_BF16X3; }
+    else { g.C = C_hi; g.plC = (bf16_t*)C_lo - (bf16_t*)C_hi; g.out_dtype = xdt; }
     g.ldc = ldc;
     return sq_launch_gemm_x3(g, (hipStream_t)stream);
 }

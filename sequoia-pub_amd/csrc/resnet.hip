@@ -14,6 +14,7 @@
 // with bias + residual + ReLU in the GEMM epilogue.  The final 7x7 average is a small memory-bound kernel.
 #include "../../include/sequoia_hip.h"
 #include "gemm.h"
+#include "x3_fmt.h"
 
 int sq_launch_bottleneck_tail_c64(const bf16_t* t1, const bf16_t* res, bf16_t* y, bf16_t* t1n, int cn,
                                   const bf16_t* w2, const bf16_t* w3, const bf16_t* w1n, size_t w2_bytes, size_t w3_bytes, size_t w1n_bytes,
@@ -152,23 +153,10 @@ __global__ void avgpool7_kernel(const T* __restrict__ in, float* __restrict__ ou
     out[idx] = acc / 49.0f;
 }
 
-// ---- split-bf16 (SQ_BF16X3) variants: every tensor is a hi plane and a lo plane of bf16 (gemm_x3.hip) ----
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hi[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-        lo[e] = pack_bf16x2(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
-    }
-}
-__device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&v)[8]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        v[2 * e] = __uint_as_float(hi[e] << 16) + __uint_as_float(lo[e] << 16);
-        v[2 * e + 1] = __uint_as_float(hi[e] & 0xffff0000u) + __uint_as_float(lo[e] & 0xffff0000u);
-    }
-}
+// ---- split (SQ_BF16X3 / SQ_F16X3) variants: every tensor is a hi plane and a lo plane of bf16 / fp16 (x3_fmt.h, gemm_x3.hip) ----
 
 // conv1 im2col (same geometry and transform as im2col_conv1_kernel), written as hi / lo planes; `plane` = elements per plane
+template <bool F16>
 __global__ __launch_bounds__(256) void im2col_conv1_x3_kernel(const uint8_t* __restrict__ src_u8, const float* __restrict__ src_f32,
                                                               bf16_t* __restrict__ out, long long plane, int n, int S, int OH) {
     __shared__ float lut[3][256];
@@ -207,13 +195,14 @@ __global__ __launch_bounds__(256) void im2col_conv1_x3_kernel(const uint8_t* __r
             v[e] = x;
         }
         u32x4 hi, lo;
-        split8(v, hi, lo);
+        x3_split8<F16>(v, hi, lo);
         *reinterpret_cast<u32x4*>(out + (size_t)m * CONV1_KP + ch * 8) = hi;
         *reinterpret_cast<u32x4*>(out + plane + (size_t)m * CONV1_KP + ch * 8) = lo;
     }
 }
 
 // MaxPool2d(3, stride 2, padding 1) on hi / lo planes: the maximum of the joined values, split again
+template <bool F16>
 __global__ __launch_bounds__(256) void maxpool3x3s2_x3_kernel(const bf16_t* __restrict__ in, long long pl_in, bf16_t* __restrict__ out,
                                                               long long pl_out, int n, int H, int OH, int C) {
     const int CG = C / 8;
@@ -234,19 +223,20 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_x3_kernel(const bf16_t* __re
                 if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)H) {
                     const size_t o = (((size_t)img * H + ih) * H + iw) * C + cg * 8;
                     float v[8];
-                    join8(*reinterpret_cast<const u32x4*>(in + o), *reinterpret_cast<const u32x4*>(in + pl_in + o), v);
+                    x3_join8<F16>(*reinterpret_cast<const u32x4*>(in + o), *reinterpret_cast<const u32x4*>(in + pl_in + o), v);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
                 }
             }
         u32x4 hi, lo;
-        split8(best, hi, lo);
+        x3_split8<F16>(best, hi, lo);
         *reinterpret_cast<u32x4*>(out + (size_t)px * C + cg * 8) = hi;
         *reinterpret_cast<u32x4*>(out + pl_out + (size_t)px * C + cg * 8) = lo;
     }
 }
 
 // AvgPool2d(7) over hi / lo planes, fp32 out (same summation order as avgpool7_kernel)
+template <bool F16>
 __global__ void avgpool7_x3_kernel(const bf16_t* __restrict__ in, long long plane, float* __restrict__ out, int n, int H, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * C) return;
@@ -255,7 +245,7 @@ __global__ void avgpool7_x3_kernel(const bf16_t* __restrict__ in, long long plan
     for (int h = 0; h < 7; ++h)
         for (int w = 0; w < 7; ++w) {
             const size_t o = (((size_t)img * H + h) * H + w) * C + c;
-            acc += bf16_to_f32(in[o]) + bf16_to_f32(in[plane + o]);
+            acc += X3Fmt<F16>::one(in[o]) + X3Fmt<F16>::one(in[plane + o]);
         }
     out[idx] = acc / 49.0f;
 }
@@ -324,7 +314,7 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                                    const float* patches_f32_nchw, int n, int S, float* features, void* workspace,
                                    size_t workspace_bytes, sq_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16 || dtype == SQ_BF16X3, "resnet50: dtype %d", dtype);
+    SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16 || dtype == SQ_BF16X3 || dtype == SQ_F16X3, "resnet50: dtype %d", dtype);
     SQ_REQUIRE(weights && bias && features && workspace, "resnet50: null pointer");
     SQ_REQUIRE((patches_u8 != nullptr) != (patches_f32_nchw != nullptr), "resnet50: give exactly one of patches_u8 / patches_f32_nchw");
     SQ_REQUIRE(n >= 1 && S >= 224 && S % 32 == 0, "resnet50: n=%d patch_size=%d (need a multiple of 32, >= 224)", n, S);
@@ -336,7 +326,9 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
         sq_set_error("resnet50: workspace %zu < required %zu", workspace_bytes, b.bytes);
         return SQ_ERR_WORKSPACE;
     }
-    const bool x3 = dtype == SQ_BF16X3;            // weights: hi plane [w_total] then lo plane [w_total]; activations: hi / lo planes
+    const bool x3 = dtype == SQ_BF16X3 || dtype == SQ_F16X3;
+    const bool f16 = dtype == SQ_F16X3;           // fp16 planes; `bias` then carries [b_total] biases followed by [b_total] per-channel scales
+    const float* colscale = x3 ? bias + lay.b_total : nullptr;      // weights: hi plane [w_total] then lo plane [w_total]; activations: hi / lo planes
     const size_t es = x3 ? 2 : sq_dtype_size(dtype);   // bytes per element of ONE plane
     const bool lp = dtype == SQ_BF16;
     auto W = [&](const sq_conv_desc& d) { return (const void*)((const char*)weights + (size_t)d.w_off * es); };
@@ -365,6 +357,7 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
         g.C = out; g.ldc = d.cout; g.out_dtype = dtype;
         if (x3) {
             g.plA = act_plane; g.plC = act_plane; g.plRes = act_plane; g.plB = lay.w_total;
+            g.x3_f16 = f16; g.colscale = colscale + d.b_off;
             return sq_launch_gemm_x3(g, st);
         }
         return sq_launch_gemm(g, dtype, st);
@@ -379,7 +372,8 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
     } else if (x3) {    // im2col (hi / lo planes) -> split-bf16 GEMM with bias + ReLU -> max-pool on the joined values
         const size_t work = (size_t)n * OH1 * OH1 * (CONV1_KP / 8);
         size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
-        hipLaunchKernelGGL(im2col_conv1_x3_kernel, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (bf16_t*)b.col, col_plane, n, S, OH1);
+        if (f16) hipLaunchKernelGGL(im2col_conv1_x3_kernel<true>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (bf16_t*)b.col, col_plane, n, S, OH1);
+        else hipLaunchKernelGGL(im2col_conv1_x3_kernel<false>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (bf16_t*)b.col, col_plane, n, S, OH1);
         SQ_LAUNCH_CHECK();
         GemmArgs g;
         const sq_conv_desc& d = lay.conv[0];
@@ -387,12 +381,13 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
         g.A = b.col; g.lda = CONV1_KP; g.a_bytes = (size_t)g.M * CONV1_KP * 2; g.plA = col_plane;
         g.B = W(d); g.ldb = CONV1_KP; g.b_bytes = w_bytes_total; g.plB = lay.w_total;
         g.bias = bias + d.b_off; g.act = SQ_ACT_RELU;
-        g.C = b.act[0]; g.ldc = 64; g.out_dtype = SQ_BF16X3; g.plC = act_plane;
+        g.C = b.act[0]; g.ldc = 64; g.out_dtype = dtype; g.plC = act_plane;
+        g.x3_f16 = f16; g.colscale = colscale + d.b_off;
         RUN(sq_launch_gemm_x3(g, st));
         const size_t workp = (size_t)n * H * H * 64 / 8;
         size_t nbp = (workp + 255) / 256; if (nbp > 65535) nbp = 65535;
-        hipLaunchKernelGGL(maxpool3x3s2_x3_kernel, dim3((int)nbp), dim3(256), 0, st, (const bf16_t*)b.act[0], act_plane, (bf16_t*)b.act[1], act_plane,
-                           n, OH1, H, 64);
+        if (f16) hipLaunchKernelGGL(maxpool3x3s2_x3_kernel<true>, dim3((int)nbp), dim3(256), 0, st, (const bf16_t*)b.act[0], act_plane, (bf16_t*)b.act[1], act_plane, n, OH1, H, 64);
+        else hipLaunchKernelGGL(maxpool3x3s2_x3_kernel<false>, dim3((int)nbp), dim3(256), 0, st, (const bf16_t*)b.act[0], act_plane, (bf16_t*)b.act[1], act_plane, n, OH1, H, 64);
         SQ_LAUNCH_CHECK();
     } else {
         {   // conv1 + bn1 + relu
@@ -496,7 +491,8 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
         }
     {
         const int total = n * 2048;
-        if (x3) hipLaunchKernelGGL(avgpool7_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], act_plane, features, n, H, 2048);
+        if (f16) hipLaunchKernelGGL(avgpool7_x3_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], act_plane, features, n, H, 2048);
+        else if (x3) hipLaunchKernelGGL(avgpool7_x3_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], act_plane, features, n, H, 2048);
         else if (lp) hipLaunchKernelGGL(avgpool7_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], features, n, H, 2048);
         else hipLaunchKernelGGL(avgpool7_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)b.act[xi], features, n, H, 2048);
         SQ_LAUNCH_CHECK();

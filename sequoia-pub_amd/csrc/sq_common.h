@@ -12,6 +12,7 @@
 
 #define SQ_F32 0
 #define SQ_BF16 1
+#define SQ_F16X3 3    // the same with fp16 planes: fp32-class accuracy (2^-23), finite range 65504 (x3_fmt.h)
 #define SQ_BF16X3 2   // split bf16: every fp32 value as hi + lo bf16 planes, three MFMAs per product (gemm_x3.hip)
 
 void sq_set_error(const char* fmt, ...);

@@ -63,6 +63,31 @@ def pack_weights(sd, lay=None):
     return w, b
 
 
+def split_planes(w, b, dtype, lay=None):
+    """Packed fp32 weights / biases -> what sq_resnet50_extract takes in the split modes: 16-bit hi plane followed by the
+    lo plane (hi = cvt(w'), lo = cvt(w' - hi)), and biases followed by the per-output-channel factors that undo w' = w * s.
+    bf16 planes: s = 1.  fp16 planes: s = the power of two that lifts the row's max |w| into [256, 512), so the lo plane
+    (<= 2^-12 of the value) stays in fp16's normal range for every weight that matters in its row."""
+    lay = lay or resnet50_layout()
+    scale = torch.ones_like(b)
+    if dtype == _lib.SQ_F16X3:
+        w = w.clone()
+        for i in range(len(lay.conv)):
+            d = lay.conv[i]
+            rows = w[d.w_off:d.w_off + d.cout * d.k_padded].view(d.cout, d.k_padded)
+            amax = rows.abs().amax(dim=1).double()
+            s = torch.where(amax > 0, torch.exp2(torch.floor(torch.log2(256.0 / amax.clamp_min(1e-30)))), torch.ones_like(amax))
+            s = s.clamp(2.0 ** -20, 2.0 ** 20).float()
+            rows.mul_(s[:, None])                      # exact: powers of two
+            scale[d.b_off:d.b_off + d.cout] = 1.0 / s
+        hdt = torch.float16
+    else:
+        hdt = torch.bfloat16
+    hi = w.to(hdt)
+    lo = (w - hi.float()).to(hdt)
+    return torch.cat([hi, lo]).view(torch.int16), torch.cat([b, scale])
+
+
 class ResNet50(nn.Module):
     """Reference-shaped container (same parameter / buffer names as src/resnet.py ResNet(Bottleneck,[3,4,6,3]))."""
 
@@ -103,12 +128,11 @@ class ResNet50(nn.Module):
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1], self._packed[2]
         w, b = pack_weights(self.state_dict())
+        if self.compute_dtype in (_lib.SQ_BF16X3, _lib.SQ_F16X3):
+            w, b = split_planes(w, b, self.compute_dtype)
         w = w.to(dev)
         if self.compute_dtype == _lib.SQ_BF16:
             w = w.to(torch.bfloat16)
-        elif self.compute_dtype == _lib.SQ_BF16X3:      # hi plane, then lo plane: w ~= hi + lo to 2^-17
-            hi = w.to(torch.bfloat16)
-            w = torch.cat([hi, (w - hi.float()).to(torch.bfloat16)])
         self._packed = (key, w, b.to(dev))
         return self._packed[1], self._packed[2]
 
