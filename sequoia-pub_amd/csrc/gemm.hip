@@ -515,8 +515,9 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return SQ_OK;
 }
 
-int g_force_tile = 0, g_dbg = 0, g_force_split = 0, g_use256 = -1, g_use_ring = -1;
+int g_force_tile = 0, g_force_split = 0, g_use256 = -1, g_use_ring = -1;
 }
+int g_dbg = 0;                   // shared with gemm_x3.hip
 extern int g_tn_force_split;
 namespace {
 
@@ -570,6 +571,7 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
 
 int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return launch_reduce(a, stream); }
 
+int g_x3_small_max_k = -1, g_x3_halo = -1;
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
@@ -577,6 +579,8 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 5) g_use256 = value;
     else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
+    else if (key == 7) g_x3_small_max_k = value;
+    else if (key == 8) g_x3_halo = value;            // split-mode 3x3: 0 = implicit GEMM only     // split-mode product: K up to this takes the 128-row shape (-1 = default / environment)
     else return SQ_ERR_ARG;
     return SQ_OK;
 }

@@ -22,6 +22,12 @@
 #include <cstdio>
 #include <cstdlib>
 
+extern int g_x3_small_max_k;     // sq_dbg_set key 7 (tests: force one block shape)
+bool sq_conv_halo_x3_eligible(const GemmArgs& a);     // conv_halo_x3.hip
+int sq_launch_conv_halo_x3(const GemmArgs& a, hipStream_t stream);
+extern int g_x3_halo;            // sq_dbg_set key 8: 0 = never take the halo-staged 3x3 kernel (tests), -1 = default
+extern int g_dbg;                // sq_dbg_set key 1: ablation switches (tools/x3_probe.py) -- 1 no stores, 2 no global loads after the prologue, 4 no MFMA, 8 no fragment reads
+
 namespace {
 
 constexpr uint32_t OOB = 0x80000000u;
@@ -32,25 +38,36 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ba
 }
 __device__ __forceinline__ u32x4 lds_read128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 
-constexpr int BM = 256, BK = 32, ROWB = 64;       // 64-byte LDS rows (32 bf16)
+constexpr int BK = 32, ROWB = 64;                 // 64-byte LDS rows (32 bf16)
 constexpr int WTM = 2;
-constexpr int A_BYTES = BM * ROWB;                // 16 KiB per plane per stage
 
-template <int WTN> struct X3Cfg {
+// Two block shapes.  BM = 256: 8 waves, three stages, one block per CU -- the long-K shape (3x3 convolutions, K >= 512).
+// BM = 128: 4 waves, two stages (64 KiB), TWO blocks per CU -- the short-K shape: with K = 64 ... 256 a tile is two to eight
+// K-steps and then an epilogue that moves as many bytes as the main loop staged (identity in, hi / lo planes out); a
+// second resident block runs its main loop under it.
+template <int BM_, int WTN> struct X3Cfg {
+    static constexpr int BM = BM_;
+    static constexpr int NT = BM_ * 2;                                 // 64 x (32 WTN) outputs per wave
     static constexpr int BN = 64 * WTN;
+    static constexpr int A_BYTES = BM * ROWB;                          // per plane per stage
     static constexpr int B_BYTES = BN * ROWB;
-    static constexpr int STAGE_BYTES = 2 * A_BYTES + 2 * B_BYTES;     // 40 / 48 KiB
-    static constexpr int NSTAGE = 3;
+    static constexpr int STAGE_BYTES = 2 * A_BYTES + 2 * B_BYTES;     // BM 256: 40 / 48 KiB; BM 128: 24 / 32 KiB
+    static constexpr int NSTAGE = BM_ == 256 ? 3 : 2;
     static constexpr int EPI_BYTES = BM * BN * 4;                      // fp32 tile staged through the idle ring
     static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES > EPI_BYTES ? NSTAGE * STAGE_BYTES : EPI_BYTES;
-    static constexpr int LOADS = 4 + (WTN == 1 ? 1 : 2);               // LDS-DMA instructions per thread per stage
+    static constexpr int ROUND = NT / 4;                               // rows one round of LDS-DMA instructions fills
+    static constexpr bool SPLIT_B = BN < ROUND;                        // BM 256, BN 64: rows 0-63 of the round = hi plane, 64-127 = lo plane
+    static constexpr int RB = SPLIT_B ? 1 : 2 * (BN / ROUND);          // B instructions per thread per stage
+    static constexpr int LOADS = 4 + RB;                               // LDS-DMA instructions per thread per stage
 };
 
-template <int WTN, bool CONV, bool F16>
-__global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
-    using Cfg = X3Cfg<WTN>;
+template <int BM_, int WTN, bool CONV, bool F16, bool PP>
+__global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(const GemmArgs p) {
+    using Cfg = X3Cfg<BM_, WTN>;
     using Fmt = X3Fmt<F16>;
+    constexpr int BM = Cfg::BM, NT = Cfg::NT, A_BYTES = Cfg::A_BYTES, ROUND = Cfg::ROUND;
     constexpr int BN = Cfg::BN, B_BYTES = Cfg::B_BYTES, STAGE_BYTES = Cfg::STAGE_BYTES, NSTAGE = Cfg::NSTAGE;
+    static_assert(!PP || BM_ == 256, "the ping-pong schedule needs the 8-wave block");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -73,8 +90,8 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
     const auto rsBh = __builtin_amdgcn_make_buffer_rsrc((void*)Bh, 0, (int)p.b_bytes, 0x00020000);
     const auto rsBl = __builtin_amdgcn_make_buffer_rsrc((void*)(Bh + p.plB), 0, (int)p.b_bytes, 0x00020000);
 
-    // loader geometry: a wave instruction fills 16 consecutive 64-byte LDS rows; 512 threads = one round of 128 rows
-    const int r0 = tid >> 2;                            // row inside a 128-row round
+    // loader geometry: a wave instruction fills 16 consecutive 64-byte LDS rows; NT threads = one round of NT / 4 rows
+    const int r0 = tid >> 2;                            // row inside a round
     const int gc = (tid & 3) ^ ((r0 >> 2) & 3);         // 16-byte chunk of the SOURCE row this lane fetches
     uint32_t a_off[2];
     int a_ih0[2], a_iw0[2];
@@ -82,7 +99,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
     bool a_ok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int m = m0 + r0 + 128 * j;
+        const int m = m0 + r0 + ROUND * j;
         a_ok[j] = m < p.M;
         if constexpr (CONV) {          // implicit GEMM: row m = output pixel (img, oh, ow); taps gathered per K-tile
             const int ohw = p.OH * p.OW;
@@ -99,12 +116,14 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
             a_off[j] = a_ok[j] ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(gc * 8)) * 2u : OOB;
         }
     }
-    // B rows: WTN == 2: one round per plane (128 rows each); WTN == 1: rows 0-63 of the round are the hi plane, 64-127 the lo plane
-    uint32_t b_off;
-    const bool b_lo_half = WTN == 1 && r0 >= 64;        // wave-uniform (waves 4-7)
-    {
-        const int n = n0 + (WTN == 1 ? (r0 & 63) : r0);
-        b_off = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(gc * 8)) * 2u : OOB;
+    // B rows: BN / ROUND rounds per plane; SPLIT_B (8 waves, BN = 64): rows 0-63 of the single round are the hi plane, 64-127 the lo plane
+    constexpr int RBP = Cfg::SPLIT_B ? 1 : BN / ROUND;  // rounds per plane
+    uint32_t b_off[RBP];
+    const bool b_lo_half = Cfg::SPLIT_B && r0 >= 64;    // wave-uniform (waves 4-7)
+#pragma unroll
+    for (int j = 0; j < RBP; ++j) {
+        const int n = n0 + (Cfg::SPLIT_B ? (r0 & 63) : r0 + ROUND * j);
+        b_off[j] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(gc * 8)) * 2u : OOB;
     }
     auto issue_loads = [&](int kt, int buf) {
         const int k0 = kt * BK;
@@ -120,38 +139,44 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
                 const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
                 const bool ok = a_ok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const uint32_t off = ok ? ((a_pix[j] + (uint32_t)(ih * p.W + iw)) * (uint32_t)p.Cin + (uint32_t)cin0) * 2u : OOB;
-                glds16(rsAh, sa + j * (128 * ROWB), off, 0);
-                glds16(rsAl, sa + A_BYTES + j * (128 * ROWB), off, 0);
+                glds16(rsAh, sa + j * (ROUND * ROWB), off, 0);
+                glds16(rsAl, sa + A_BYTES + j * (ROUND * ROWB), off, 0);
             }
-            const uint32_t ob = k_ok ? b_off + (uint32_t)(k0 * 2) : OOB;
-            if constexpr (WTN == 1) {
-                if (b_lo_half) glds16(rsBl, sb, ob, 0); else glds16(rsBh, sb, ob, 0);
-            } else {
-                glds16(rsBh, sb, ob, 0);
-                glds16(rsBl, sb + B_BYTES, ob, 0);
+#pragma unroll
+            for (int j = 0; j < RBP; ++j) {
+                const uint32_t ob = k_ok ? b_off[j] + (uint32_t)(k0 * 2) : OOB;
+                if constexpr (Cfg::SPLIT_B) {
+                    if (b_lo_half) glds16(rsBl, sb, ob, 0); else glds16(rsBh, sb, ob, 0);
+                } else {
+                    glds16(rsBh, sb + j * (ROUND * ROWB), ob, 0);
+                    glds16(rsBl, sb + B_BYTES + j * (ROUND * ROWB), ob, 0);
+                }
             }
         } else {
-            const int soff = k0 * 2;
+            const int soff = (p.dbg & 16) ? k0 * 4 : k0 * 2;     // dbg 16 (x3_probe.py): hi / lo interleaved per 32-element block
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t off = k_ok ? a_off[j] : OOB;
-                glds16(rsAh, sa + j * (128 * ROWB), off, soff);
-                glds16(rsAl, sa + A_BYTES + j * (128 * ROWB), off, soff);
+                glds16(rsAh, sa + j * (ROUND * ROWB), off, soff);
+                glds16(rsAl, sa + A_BYTES + j * (ROUND * ROWB), off, soff);
             }
-            const uint32_t ob = k_ok ? b_off : OOB;
-            if constexpr (WTN == 1) {
-                if (b_lo_half) glds16(rsBl, sb, ob, soff); else glds16(rsBh, sb, ob, soff);
-            } else {
-                glds16(rsBh, sb, ob, soff);
-                glds16(rsBl, sb + B_BYTES, ob, soff);
+#pragma unroll
+            for (int j = 0; j < RBP; ++j) {
+                const uint32_t ob = k_ok ? b_off[j] : OOB;
+                if constexpr (Cfg::SPLIT_B) {
+                    if (b_lo_half) glds16(rsBl, sb, ob, soff); else glds16(rsBh, sb, ob, soff);
+                } else {
+                    glds16(rsBh, sb + j * (ROUND * ROWB), ob, soff);
+                    glds16(rsBl, sb + B_BYTES + j * (ROUND * ROWB), ob, soff);
+                }
             }
         }
     };
 
     // epilogue operands that do not depend on the accumulators are requested before the K loop
     constexpr int BN8 = BN / 8;
-    constexpr int RPI = 512 / BN8;            // rows per epilogue iteration (32 / 64)
-    constexpr int ITER = BM / RPI;            // 8 / 4
+    constexpr int RPI = NT / BN8;             // rows per epilogue iteration
+    constexpr int ITER = BM / RPI;            // 8 (BN = 128) / 4 (BN = 64)
     const int e_c8 = tid % BN8, e_rbase = tid / BN8;
     const int e_n = n0 + e_c8 * 8;
     const bool e_live = e_n < p.N;            // N % 8 == 0 (launcher)
@@ -229,20 +254,111 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
 
     const int nk = (p.K + BK - 1) / BK;
     issue_loads(0, 0);
-    if (nk > 1) issue_loads(1, 1);
-    int cur = 0, nxt2 = 2;                              // ring positions of tile kt and tile kt+2
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {                              // tile kt landed (this thread's part); tile kt+1 may be in flight
+    if (NSTAGE == 3 && nk > 1) issue_loads(1, 1);
+    if constexpr (PP) {
+        // Ping-pong schedule: the two waves of a SIMD (w and w + 4) belong to different groups that run half a K-tile apart.
+        // A wave alternates a LOAD phase (all 16 fragment reads of tile t into registers, its share of tile t+2's LDS-DMA,
+        // the counted wait for its share of tile t+1) and a MATRIX phase (the 24 MFMAs of tile t, registers only); one
+        // block-wide barrier per phase keeps group 0 in its matrix phase exactly while group 1 loads and vice versa, so
+        // the SIMD's matrix pipe has one wave feeding it at all times and address arithmetic, DMA issue and LDS latency
+        // sit under the partner's MFMAs.  Hazards: tile t is read in phases 2t (group 0) and 2t+1 (group 1); its buffer
+        // is overwritten by tile t+3, issued in phases 2t+2 / 2t+3 -- behind the barrier that ends phase 2t+1; a wave's
+        // share of tile t+1 is waited for before the barrier that ends its load phase of tile t, i.e. two barriers before
+        // the first read of tile t+1 by either group.
+        const int grp = wave >> 2;
+        u32x4 ah[2][WTM], al[2][WTM], bh[2][WTN], bl[2][WTN];
+        auto read_frags = [&](int buf) {
+            const char* st = smem + buf * STAGE_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < WTM; ++i) { ah[s][i] = lds_read128(st + fa_off[i][s]); al[s][i] = lds_read128(st + fa_off[i][s] + A_BYTES); }
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) { bh[s][j] = lds_read128(st + fb_off[j][s]); bl[s][j] = lds_read128(st + fb_off[j][s] + B_BYTES); }
+            }
+        };
+        auto mma_all = [&]() {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) Fmt::mma(al[s][i], bh[s][j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bl[s][j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bh[s][j], acc[i][j]);
+            }
+        };
+        if (nk > 1) {
             if constexpr (Cfg::LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();                   // everybody's part; and tile kt-1's buffer is free
-        if (kt + 2 < nk) issue_loads(kt + 2, nxt2);
-        compute(cur);
-        cur = cur == NSTAGE - 1 ? 0 : cur + 1;
-        nxt2 = nxt2 == NSTAGE - 1 ? 0 : nxt2 + 1;
+        __builtin_amdgcn_s_barrier();                   // tile 0 is in LDS
+        if (grp == 1) __builtin_amdgcn_s_barrier();     // group 1 starts one phase later
+        int cur = 0, nxt2 = 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            // ---- load phase
+            if (!(p.dbg & 8) || kt == 0) read_frags(cur);
+            if (kt + 2 < nk) {
+                if (!(p.dbg & 2)) issue_loads(kt + 2, nxt2);
+                if constexpr (Cfg::LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this thread's share of tile kt+1 landed
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- matrix phase
+            __builtin_amdgcn_s_setprio(1);
+            if (!(p.dbg & 4)) mma_all();
+            else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                    for (int i = 0; i < WTM; ++i) asm volatile("" :: "v"(ah[s][i]), "v"(al[s][i]));
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) asm volatile("" :: "v"(bh[s][j]), "v"(bl[s][j]));
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0 || kt + 1 < nk) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+            nxt2 = nxt2 == NSTAGE - 1 ? 0 : nxt2 + 1;
+        }
+    } else if constexpr (NSTAGE == 3) {
+        int cur = 0, nxt2 = 2;                              // ring positions of tile kt and tile kt+2
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {                              // tile kt landed (this thread's part); tile kt+1 may be in flight
+                if constexpr (Cfg::LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                   // everybody's part; and tile kt-1's buffer is free
+            if (kt + 2 < nk) issue_loads(kt + 2, nxt2);
+            compute(cur);
+            cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+            nxt2 = nxt2 == NSTAGE - 1 ? 0 : nxt2 + 1;
+        }
+    } else {
+        // two stages: tile kt+1 streams in under the MFMAs of tile kt; the co-resident block covers the wait
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // tile kt landed everywhere; tile kt-1's buffer is free
+            if (kt + 1 < nk) issue_loads(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+        }
     }
     __syncthreads();                                    // all MFMAs read their fragments: the ring becomes the fp32 stage
 
@@ -298,6 +414,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+            if (p.dbg & 1) continue;
             if (c32) {
                 float* d = c32 + (long long)m * p.ldc + e_n;
                 *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
@@ -313,28 +430,36 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(const GemmArgs p) {
     }
 }
 
-template <int WTN, bool F16>
+template <int BM_, int WTN, bool F16, bool PP>
 int launch_x3(const GemmArgs& a, hipStream_t stream) {
-    using Cfg = X3Cfg<WTN>;
+    using Cfg = X3Cfg<BM_, WTN>;
     static bool attr = false;
     if (!attr) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<WTN, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<WTN, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<BM_, WTN, false, F16, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<BM_, WTN, true, F16, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr = true;
     }
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + Cfg::BN - 1) / Cfg::BN);
-    const dim3 grid(tiles), block(512);
-    if (a.conv) hipLaunchKernelGGL((gemm_x3_kernel<WTN, true, F16>), grid, block, Cfg::LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL((gemm_x3_kernel<WTN, false, F16>), grid, block, Cfg::LDS_BYTES, stream, a);
+    const int tiles = ((a.M + BM_ - 1) / BM_) * ((a.N + Cfg::BN - 1) / Cfg::BN);
+    const dim3 grid(tiles), block(Cfg::NT);
+    if (a.conv) hipLaunchKernelGGL((gemm_x3_kernel<BM_, WTN, true, F16, PP>), grid, block, Cfg::LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((gemm_x3_kernel<BM_, WTN, false, F16, PP>), grid, block, Cfg::LDS_BYTES, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
+}
+
+template <int BM_, bool PP>
+int launch_x3_fmt(const GemmArgs& a, hipStream_t stream) {
+    if (a.x3_f16) return a.N % 128 == 0 ? launch_x3<BM_, 2, true, PP>(a, stream) : launch_x3<BM_, 1, true, PP>(a, stream);
+    return a.N % 128 == 0 ? launch_x3<BM_, 2, false, PP>(a, stream) : launch_x3<BM_, 1, false, PP>(a, stream);
 }
 
 }  // namespace
 
 // C = act(alpha * A.B^T + bias + res): A, B (and res, and C unless out_dtype == SQ_F32) as hi / lo bf16 planes;
 // a.A / a.B / a.res / a.C point at the hi plane, the lo plane sits plA / plB / plRes / plC ELEMENTS behind it.
-int sq_launch_gemm_x3(const GemmArgs& a, hipStream_t stream) {
+int sq_launch_gemm_x3(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    a.dbg |= g_dbg;
     SQ_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch == 1, "gemm_x3: empty or batched problem M=%d N=%d K=%d batch=%d", a.M, a.N, a.K, a.batch);
     SQ_REQUIRE(a.K % 8 == 0 && a.ldb % 8 == 0 && a.N % 8 == 0, "gemm_x3: K=%d / ldb=%d / N=%d must be multiples of 8", a.K, a.ldb, a.N);
     SQ_REQUIRE(a.plA != 0 && a.plB != 0 && (a.plA & 7) == 0 && (a.plB & 7) == 0, "gemm_x3: operand plane strides must be non-zero multiples of 8 elements");
@@ -358,9 +483,13 @@ int sq_launch_gemm_x3(const GemmArgs& a, hipStream_t stream) {
         snprintf(name, sizeof(name), "%s_%s_M%d_N%d_K%d", a.conv ? "conv" : "gemm", a.x3_f16 ? "f16x3" : "bf16x3", a.M, a.N, a.K);
         prof = sq_prof_begin(name, flops, bytes, stream);
     }
-    int rc;
-    if (a.x3_f16) rc = a.N % 128 == 0 ? launch_x3<2, true>(a, stream) : launch_x3<1, true>(a, stream);
-    else rc = a.N % 128 == 0 ? launch_x3<2, false>(a, stream) : launch_x3<1, false>(a, stream);
+    static const bool lockstep = sq_env_flag("SQ_X3_LOCKSTEP");     // A/B switch: the one-barrier-per-tile schedule (all waves in step)
+    static int env_max_k = -1;                                       // products with K up to this take the 128-row, two-blocks-per-CU shape
+    if (env_max_k < 0) { const char* e = getenv("SQ_X3_SMALL_MAXK"); env_max_k = e ? atoi(e) : 256; }
+    const int small_max_k = g_x3_small_max_k >= 0 ? g_x3_small_max_k : env_max_k;
+    const int rc = (g_x3_halo != 0 && sq_conv_halo_x3_eligible(a)) ? sq_launch_conv_halo_x3(a, stream)
+                 : a.K <= small_max_k ? launch_x3_fmt<128, false>(a, stream)
+                 : lockstep ? launch_x3_fmt<256, false>(a, stream) : launch_x3_fmt<256, true>(a, stream);
     if (prof >= 0) sq_prof_end(prof, stream);
     return rc;
 }

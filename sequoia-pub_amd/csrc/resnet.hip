@@ -29,6 +29,8 @@ int sq_launch_bottleneck_chain_c128(const bf16_t* t2, const bf16_t* res, bf16_t*
                                     long long P, hipStream_t stream);
 int sq_launch_conv1_pool_bf16(const uint8_t* u8, const float* f32_nchw, const bf16_t* w152, const float* bias, bf16_t* out,
                               int n, int S, hipStream_t stream);
+int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, const uint16_t* w152_hi, long long w_plane, const float* bias,
+                            const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream);
 
 namespace {
 
@@ -155,86 +157,6 @@ __global__ void avgpool7_kernel(const T* __restrict__ in, float* __restrict__ ou
 
 // ---- split (SQ_BF16X3 / SQ_F16X3) variants: every tensor is a hi plane and a lo plane of bf16 / fp16 (x3_fmt.h, gemm_x3.hip) ----
 
-// conv1 im2col (same geometry and transform as im2col_conv1_kernel), written as hi / lo planes; `plane` = elements per plane
-template <bool F16>
-__global__ __launch_bounds__(256) void im2col_conv1_x3_kernel(const uint8_t* __restrict__ src_u8, const float* __restrict__ src_f32,
-                                                              bf16_t* __restrict__ out, long long plane, int n, int S, int OH) {
-    __shared__ float lut[3][256];
-    __shared__ int8_t t_kh[CONV1_KP], t_kw[CONV1_KP], t_c[CONV1_KP];
-    for (int i = threadIdx.x; i < 3 * 256; i += 256) {
-        const int c = i >> 8, v = i & 255;
-        const float p = (float)v / 255.0f;
-        lut[c][v] = (p - BN_MEAN[c]) / BN_STD[c];
-    }
-    for (int k = threadIdx.x; k < CONV1_KP; k += 256) {
-        const int tap = k / 3;
-        t_c[k] = k < CONV1_K ? (int8_t)(k - tap * 3) : (int8_t)-1;
-        t_kh[k] = (int8_t)(tap / 7);
-        t_kw[k] = (int8_t)(tap % 7);
-    }
-    __syncthreads();
-    constexpr int CH = CONV1_KP / 8;
-    const uint32_t total = (uint32_t)n * OH * OH * CH;
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const uint32_t ch = idx % CH;
-        const uint32_t m = idx / CH;
-        const uint32_t t1 = m / OH;
-        const int ow = (int)(m - t1 * OH), img = (int)(t1 / OH), oh = (int)(t1 - (uint32_t)img * OH);
-        const int ih0 = oh * 2 - 3, iw0 = ow * 2 - 3;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = ch * 8 + e;
-            const int c = t_c[k];
-            const int ih = ih0 + t_kh[k], iw = iw0 + t_kw[k];
-            float x = 0.f;
-            if (c >= 0 && (unsigned)ih < (unsigned)S && (unsigned)iw < (unsigned)S) {
-                if (src_u8) x = lut[c][src_u8[(((size_t)img * S + ih) * S + iw) * 3 + c]];
-                else x = src_f32[(((size_t)img * 3 + c) * S + ih) * S + iw];
-            }
-            v[e] = x;
-        }
-        u32x4 hi, lo;
-        x3_split8<F16>(v, hi, lo);
-        *reinterpret_cast<u32x4*>(out + (size_t)m * CONV1_KP + ch * 8) = hi;
-        *reinterpret_cast<u32x4*>(out + plane + (size_t)m * CONV1_KP + ch * 8) = lo;
-    }
-}
-
-// MaxPool2d(3, stride 2, padding 1) on hi / lo planes: the maximum of the joined values, split again
-template <bool F16>
-__global__ __launch_bounds__(256) void maxpool3x3s2_x3_kernel(const bf16_t* __restrict__ in, long long pl_in, bf16_t* __restrict__ out,
-                                                              long long pl_out, int n, int H, int OH, int C) {
-    const int CG = C / 8;
-    const uint32_t total = (uint32_t)n * OH * OH * CG;
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const uint32_t cg = idx % CG;
-        const uint32_t px = idx / CG;
-        const uint32_t t1 = px / OH;
-        const int ow = (int)(px - t1 * OH), img = (int)(t1 / OH), oh = (int)(t1 - (uint32_t)img * OH);
-        float best[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)H) {
-                    const size_t o = (((size_t)img * H + ih) * H + iw) * C + cg * 8;
-                    float v[8];
-                    x3_join8<F16>(*reinterpret_cast<const u32x4*>(in + o), *reinterpret_cast<const u32x4*>(in + pl_in + o), v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
-                }
-            }
-        u32x4 hi, lo;
-        x3_split8<F16>(best, hi, lo);
-        *reinterpret_cast<u32x4*>(out + (size_t)px * C + cg * 8) = hi;
-        *reinterpret_cast<u32x4*>(out + pl_out + (size_t)px * C + cg * 8) = lo;
-    }
-}
-
 // AvgPool2d(7) over hi / lo planes, fp32 out (same summation order as avgpool7_kernel)
 template <bool F16>
 __global__ void avgpool7_x3_kernel(const bf16_t* __restrict__ in, long long plane, float* __restrict__ out, int n, int H, int C) {
@@ -275,7 +197,7 @@ void rn_bufs(int dtype, int n, int S, char* base, RnBufs* o) {
     auto take = [&](size_t bytes) { off = sq_align_up(off, 256); char* p = base ? base + off : nullptr; off += bytes; return (void*)p; };
     const size_t es = sq_dtype_size(dtype);
     const size_t OH = S / 2;
-    o->col = dtype == SQ_BF16 ? nullptr : take((size_t)n * OH * OH * CONV1_KP * es);    // bf16: fused stem, no im2col matrix
+    o->col = dtype == SQ_F32 ? take((size_t)n * OH * OH * CONV1_KP * es) : nullptr;    // bf16 and the split modes: fused stem, no im2col matrix
     const size_t act = (size_t)n * OH * OH * 64 * es;          // largest activation: conv1 out == layer1 out
     for (int i = 0; i < 5; ++i) o->act[i] = take(act);
     o->bytes = sq_align_up(off, 256);
@@ -335,9 +257,8 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
     const size_t w_bytes_total = (size_t)lay.w_total * es;
     const size_t act_cap = (size_t)n * (S / 2) * (S / 2) * 64 * es;
     const long long act_plane = (long long)n * (S / 2) * (S / 2) * 64;            // x3: elements between an activation's hi and lo plane
-    const long long col_plane = (long long)n * (S / 2) * (S / 2) * CONV1_KP;
-    SQ_REQUIRE(act_cap < (1ull << 31) && (lp || (size_t)n * (S / 2) * (S / 2) * CONV1_KP * es < (1ull << 31)),
-               "resnet50: sub-batch of %d patches exceeds the 2 GiB buffer-descriptor limit (bf16: <= 1300 patches of 224, bf16x3: <= 560, fp32: <= 280)", n);
+    SQ_REQUIRE(act_cap < (1ull << 31) && (lp || x3 || (size_t)n * (S / 2) * (S / 2) * CONV1_KP * es < (1ull << 31)),
+               "resnet50: sub-batch of %d patches exceeds the 2 GiB buffer-descriptor limit (bf16 and the split modes: <= 1300 patches of 224, fp32: <= 280)", n);
 
     // conv as a GEMM launch.  in: NHWC [n, H, H, cin];  out: [n, OH, OH, cout]
     auto conv = [&](const sq_conv_desc& d, const void* in, int H, void* out, int OH, const void* res, int act) -> int {
@@ -369,26 +290,10 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
     if (lp) {           // conv1 + bn1 + relu + maxpool in one kernel (conv1.hip)
         const sq_conv_desc& d = lay.conv[0];
         RUN(sq_launch_conv1_pool_bf16(patches_u8, patches_f32_nchw, (const bf16_t*)W(d), bias + d.b_off, (bf16_t*)b.act[1], n, S, st));
-    } else if (x3) {    // im2col (hi / lo planes) -> split-bf16 GEMM with bias + ReLU -> max-pool on the joined values
-        const size_t work = (size_t)n * OH1 * OH1 * (CONV1_KP / 8);
-        size_t nb = (work + 255) / 256; if (nb > 65535) nb = 65535;
-        if (f16) hipLaunchKernelGGL(im2col_conv1_x3_kernel<true>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (bf16_t*)b.col, col_plane, n, S, OH1);
-        else hipLaunchKernelGGL(im2col_conv1_x3_kernel<false>, dim3((int)nb), dim3(256), 0, st, patches_u8, patches_f32_nchw, (bf16_t*)b.col, col_plane, n, S, OH1);
-        SQ_LAUNCH_CHECK();
-        GemmArgs g;
+    } else if (x3) {    // the same fusion on hi / lo planes (conv1_x3.hip)
         const sq_conv_desc& d = lay.conv[0];
-        g.M = n * OH1 * OH1; g.N = 64; g.K = CONV1_KP;
-        g.A = b.col; g.lda = CONV1_KP; g.a_bytes = (size_t)g.M * CONV1_KP * 2; g.plA = col_plane;
-        g.B = W(d); g.ldb = CONV1_KP; g.b_bytes = w_bytes_total; g.plB = lay.w_total;
-        g.bias = bias + d.b_off; g.act = SQ_ACT_RELU;
-        g.C = b.act[0]; g.ldc = 64; g.out_dtype = dtype; g.plC = act_plane;
-        g.x3_f16 = f16; g.colscale = colscale + d.b_off;
-        RUN(sq_launch_gemm_x3(g, st));
-        const size_t workp = (size_t)n * H * H * 64 / 8;
-        size_t nbp = (workp + 255) / 256; if (nbp > 65535) nbp = 65535;
-        if (f16) hipLaunchKernelGGL(maxpool3x3s2_x3_kernel<true>, dim3((int)nbp), dim3(256), 0, st, (const bf16_t*)b.act[0], act_plane, (bf16_t*)b.act[1], act_plane, n, OH1, H, 64);
-        else hipLaunchKernelGGL(maxpool3x3s2_x3_kernel<false>, dim3((int)nbp), dim3(256), 0, st, (const bf16_t*)b.act[0], act_plane, (bf16_t*)b.act[1], act_plane, n, OH1, H, 64);
-        SQ_LAUNCH_CHECK();
+        RUN(sq_launch_conv1_pool_x3(f16, patches_u8, patches_f32_nchw, (const uint16_t*)W(d), lay.w_total, bias + d.b_off, colscale + d.b_off,
+                                    (uint16_t*)b.act[1], act_plane, n, S, st));
     } else {
         {   // conv1 + bn1 + relu
             const size_t work = (size_t)n * OH1 * OH1 * (CONV1_KP / 8);

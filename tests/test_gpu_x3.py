@@ -86,10 +86,21 @@ SHAPES = [(256, 128, 64), (1000, 64, 256), (300, 520, 1032), (129, 72, 40), (410
 TOL = {0: (3e-5, 1.6e-5), 1: (2e-6, 5e-7)}
 
 
+@pytest.fixture(params=["auto", "rows256", "rows128"])
+def block_shape(request):
+    """Both block shapes of gemm_x3.hip on every problem: the 8-wave 256-row ping-pong kernel and the 4-wave 128-row,
+    two-blocks-per-CU kernel (the launcher picks by K; sq_dbg_set key 7 forces one)."""
+    lib = _lib.lib()
+    lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.sq_dbg_set(7, {"auto": -1, "rows256": 0, "rows128": 1 << 30}[request.param])
+    yield request.param
+    lib.sq_dbg_set(7, -1)
+
+
 @pytest.mark.parametrize("fmt", [0, 1])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 @pytest.mark.parametrize("act,use_res", [(0, False), (2, True)])
-def test_linear_x3_matches_three_term_formula_and_true_product(M, N, K, act, use_res, fmt):
+def test_linear_x3_matches_three_term_formula_and_true_product(M, N, K, act, use_res, fmt, block_shape):
     _lib.require_gpu()
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + act)
     A = torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3
@@ -109,7 +120,7 @@ def test_linear_x3_matches_three_term_formula_and_true_product(M, N, K, act, use
 
 @pytest.mark.parametrize("fmt", [0, 1])
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,H", [(64, 64, 3, 1, 1, 14), (128, 128, 3, 2, 1, 28), (256, 512, 1, 2, 0, 14), (32, 72, 3, 1, 1, 9)])
-def test_conv_x3_implicit_gemm(Cin, Cout, k, stride, pad, H, fmt):
+def test_conv_x3_implicit_gemm(Cin, Cout, k, stride, pad, H, fmt, block_shape):
     """The implicit-GEMM loader (taps gathered per K-tile, zero padding through the buffer descriptor) against
     torch.nn.functional.conv2d in fp64 on the joined operands, image borders inside a tile (n = 3 images)."""
     _lib.require_gpu()
@@ -127,6 +138,36 @@ def test_conv_x3_implicit_gemm(Cin, Cout, k, stride, pad, H, fmt):
     out = run_x3(x.reshape(-1, Cin), w.reshape(Cout, k * k * Cin), bias, None, 2, f32_out=True,
                  conv=(n, H, H, Cin, OH, OH, k, stride, pad), M=n * OH * OH, fmt=fmt)
     assert rel_err(out, ref) < TOL[fmt][0], rel_err(out, ref)
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("halo", [-1, 0])
+@pytest.mark.parametrize("Cin,Cout,H,n", [(128, 128, 28, 2), (256, 256, 14, 3), (64, 128, 7, 11), (32, 256, 31, 1), (96, 128, 5, 23)])
+def test_conv_x3_halo_staged_3x3(Cin, Cout, H, n, halo, fmt):
+    """conv_halo_x3.hip (input tile resident in LDS, all nine taps from one staged copy; taken for 3x3 / stride 1 / pad 1,
+    maps <= 31 wide, N % 128 == 0) against conv2d in fp64 on the joined operands -- image borders and image boundaries
+    inside a 256-pixel tile, a ragged last tile -- and the implicit-GEMM form (sq_dbg_set key 8 = 0) on the same problem."""
+    _lib.require_gpu()
+    lib = _lib.lib()
+    lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    g = torch.Generator().manual_seed(Cin + Cout + H + n)
+    x = torch.randn(n, H, H, Cin, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * (1.0 / np.sqrt(9 * Cin))
+    bias = torch.randn(Cout, generator=g)
+    xh, xl = split(x, fmt)
+    wh, wl = split(w * WSCALE[fmt], fmt)
+    xj, wj = xh.double() + xl.double(), (wh.double() + wl.double()) / WSCALE[fmt]
+    ref = torch.nn.functional.conv2d(xj.permute(0, 3, 1, 2), wj.permute(0, 3, 1, 2), bias.double(), stride=1, padding=1)
+    ref = torch.relu(ref).permute(0, 2, 3, 1).reshape(n * H * H, Cout)
+    lib.sq_dbg_set(8, halo)
+    try:
+        out = run_x3(x.reshape(-1, Cin), w.reshape(Cout, 9 * Cin), bias, None, 2, f32_out=True, conv=(n, H, H, Cin, H, H, 3, 1, 1), M=n * H * H, fmt=fmt)
+        planes_out = run_x3(x.reshape(-1, Cin), w.reshape(Cout, 9 * Cin), bias, None, 2, conv=(n, H, H, Cin, H, H, 3, 1, 1), M=n * H * H, fmt=fmt)
+    finally:
+        lib.sq_dbg_set(8, -1)
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < TOL[fmt][0], rel_err(out, ref)
+    assert rel_err(planes_out, out) < TOL[fmt][1], rel_err(planes_out, out)
 
 
 def _model(mode):
