@@ -11,7 +11,9 @@
 //   per 256 x 128 output tile and 32-channel block:   A 40 KB (once) + B 9 x 16 KB     instead of     9 x (32 + 16) KB.
 // 8 waves (4 x 2, 64 x 64 per wave), 24 MFMAs per wave and step.  LDS: two input-block buffers (hi + lo, the next block's
 // rows arrive while the current one is multiplied) + a four-stage ring of weight tiles (three in flight, counted vmcnt +
-// raw s_barrier) = 144 KiB, one block per CU.  64-byte LDS rows, 16-byte chunk ^= (row >> 2) & 3 on the SOURCE address.
+// raw s_barrier) = 144 KiB, one block per CU.  Maps 32 ... 63 wide (the 56 x 56 stage) stage 384 rows per block; its
+// 64-channel output uses a 256 x 64 tile (64 x 32 per wave) whose weight tile is one LDS-DMA instruction for both planes.
+// 64-byte LDS rows, 16-byte chunk ^= (row >> 2) & 3 on the SOURCE address.
 // K is walked channel-block-major: the fp32 accumulation order differs from the tap-major implicit GEMM (fp32 rounding).
 #include "gemm.h"
 #include "x3_fmt.h"
@@ -29,26 +31,33 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ba
 }
 __device__ __forceinline__ u32x4 lds128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 
-constexpr int BM = 256, BN = 128, ROWB = 64, CB = 32;
-constexpr int HALO_ROWS = 320;                    // >= 256 + 2 W + 2 rows, W <= 31
-constexpr int HP_BYTES = HALO_ROWS * ROWB;        // one plane of one input block: 20 KiB
-constexpr int HALO_BYTES = 2 * HP_BYTES;          // hi plane, then lo plane
-constexpr int BP_BYTES = BN * ROWB;               // one plane of one weight tile [128 n][32 k]: 8 KiB
-constexpr int BT_BYTES = 2 * BP_BYTES;
+constexpr int BM = 256, ROWB = 64, CB = 32;
 constexpr int NB = 4;                             // weight ring stages
-constexpr int LDS_BYTES = 2 * HALO_BYTES + NB * BT_BYTES;      // 147456
-constexpr int HL = HALO_BYTES / 16 / 512;         // 5 LDS-DMA instructions per thread and input block
-constexpr int PSLOTS = HP_BYTES / 16;             // 16-byte slots per plane (1280 = 20 wave instructions)
 
-template <int TAP> struct TapWait {               // loads issued after weight tile g's own loads when tile g is waited for:
-    // two newer weight tiles (2 loads each) + the next input block (HL loads) if it was issued in one of the last two
-    // iterations (it is issued at tap 4, in front of that iteration's weight tile)
-    static constexpr int value = 4 + ((TAP == 5 || TAP == 6) ? HL : 0);
+// WTN: 32-column MFMA tiles per wave (BN = 64 WTN: 128 for the 28 x 28 ... 7 x 7 stages, 64 for the 56 x 56 stage);
+// HROWS: staged input rows per block, >= 256 + 2 W + 2 (320: maps up to 31 wide, 384: up to 63 wide)
+template <int WTN, int HROWS> struct HxCfg {
+    static constexpr int BN = 64 * WTN;
+    static constexpr int HP_BYTES = HROWS * ROWB;          // one plane of one input block: 20 / 24 KiB
+    static constexpr int HALO_BYTES = 2 * HP_BYTES;        // hi plane, then lo plane
+    static constexpr int BP_BYTES = BN * ROWB;             // one plane of one weight tile [BN n][32 k]: 8 / 4 KiB
+    static constexpr int BT_BYTES = 2 * BP_BYTES;
+    static constexpr int RING = 2 * HALO_BYTES + NB * BT_BYTES;
+    static constexpr int EPI = BM * BN * 4;
+    static constexpr int LDS_BYTES = RING > EPI ? RING : EPI;     // 144 KiB (320, 128) ... 160 KiB (384, 128); 128 KiB (384, 64)
+    static constexpr int HL = HALO_BYTES / 16 / 512;       // 5 / 6 LDS-DMA instructions per thread and input block
+    static constexpr int PSLOTS = HP_BYTES / 16;           // 16-byte slots per plane: 20 / 24 wave instructions
+    static constexpr int WL = WTN;                         // LDS-DMA instructions per thread and weight tile (BN = 64: both planes in one)
 };
 
-template <bool F16>
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WTN, int HROWS, bool F16>
 __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
     using Fmt = X3Fmt<F16>;
+    using Cfg = HxCfg<WTN, HROWS>;
+    constexpr int BN = Cfg::BN, HP_BYTES = Cfg::HP_BYTES, HALO_BYTES = Cfg::HALO_BYTES, BP_BYTES = Cfg::BP_BYTES, BT_BYTES = Cfg::BT_BYTES;
+    constexpr int HL = Cfg::HL, PSLOTS = Cfg::PSLOTS, WL = Cfg::WL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const HB = smem;                        // [2][HALO_BYTES]
     char* const WR = smem + 2 * HALO_BYTES;       // [NB][BT_BYTES]
@@ -77,13 +86,14 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
     const auto rsBh = __builtin_amdgcn_make_buffer_rsrc((void*)Bh, 0, (int)p.b_bytes, 0x00020000);
     const auto rsBl = __builtin_amdgcn_make_buffer_rsrc((void*)(Bh + p.plB), 0, (int)p.b_bytes, 0x00020000);
 
-    // input block: rows [halo0, halo0 + HALO_ROWS) x channels [32 cb, 32 cb + 32), hi plane then lo plane.  Instruction u of
-    // a wave covers slots [u*512 + wave*64, +64): u < 2 hi, u > 2 lo, u == 2 hi for waves 0-3 and lo for waves 4-7.
+    // input block: rows [halo0, halo0 + HROWS) x channels [32 cb, 32 cb + 32), hi plane then lo plane.  Instruction u of a wave
+    // covers slots [u*512 + wave*64, +64); a plane is a whole number of wave instructions, so the plane is wave-uniform
+    // (HROWS 320: u < 2 hi, u > 2 lo, u == 2 hi for waves 0-3 and lo for waves 4-7).
     auto issue_halo = [&](int cb, int buf) {
 #pragma unroll
         for (int u = 0; u < HL; ++u) {
             const int q = u * 512 + tid;
-            const bool lo = u > 2 || (u == 2 && wave >= 4);      // wave-uniform
+            const bool lo = u * 512 + wave * 64 >= PSLOTS;       // wave-uniform
             const int s = lo ? q - PSLOTS : q;
             const int row = s >> 2, c = (s & 3) ^ ((row >> 2) & 3);
             const int px = halo0 + row;
@@ -93,13 +103,19 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
             if (lo) glds16(rsAl, dst, off); else glds16(rsAh, dst, off);
         }
     };
-    const int br0 = tid >> 2, bc = (tid & 3) ^ ((br0 >> 2) & 3);
+    // weight tile [n0 + n][tap*C + cb*32 + 0..31], hi plane then lo plane.  BN = 128: one instruction per plane;
+    // BN = 64: one instruction for both (waves 0-3 the hi plane, waves 4-7 the lo plane)
+    const int br0 = (tid >> 2) & (BN - 1), bc = (tid & 3) ^ ((br0 >> 2) & 3);
     const uint32_t b_row = (uint32_t)(n0 + br0) * (uint32_t)p.ldb + (uint32_t)(bc * 8);
-    auto issue_wtile = [&](int cb, int tap, int stage) {     // weights [n0 + n][tap*C + cb*32 + 0..31], hi plane then lo plane
+    auto issue_wtile = [&](int cb, int tap, int stage) {
         const uint32_t off = (b_row + (uint32_t)(tap * C + cb * CB)) * 2u;
         char* dst = WR + stage * BT_BYTES + wave * 1024;
-        glds16(rsBh, dst, off);
-        glds16(rsBl, dst + BP_BYTES, off);
+        if constexpr (WTN == 2) {
+            glds16(rsBh, dst, off);
+            glds16(rsBl, dst + BP_BYTES, off);
+        } else {
+            if (wave >= 4) glds16(rsBl, dst, off); else glds16(rsBh, dst, off);
+        }
     };
 
     // this lane's two output pixels: halo rows of the centre tap and tap validity
@@ -121,12 +137,12 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
         }
         mask[i] = mk;
     }
-    int fb_off[2][2];
+    int fb_off[WTN][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = wn * 64 + j * 32 + l31;
+        for (int j = 0; j < WTN; ++j) {
+            const int row = wn * (32 * WTN) + j * 32 + l31;
             fb_off[j][s] = row * ROWB + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4);
         }
 
@@ -148,11 +164,11 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
         for (int e = 0; e < 4; ++e) { scale8[e] = p.alpha * t0[e]; scale8[4 + e] = p.alpha * t1[e]; }
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][WTN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -166,15 +182,12 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
     auto step = [&](int cb, auto tapc) {
         constexpr int TAP = decltype(tapc)::value;
         const int g = cb * 9 + TAP;
-        // wait for weight tile g (and everything older: the input block this tap reads)
-        if (g + 2 < ntile) {
-            if constexpr (TapWait<TAP>::value == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        } else if (g + 1 < ntile) {
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // wait for weight tile g (and everything older: the input block this tap reads).  Issued after tile g's own loads:
+        // two newer weight tiles (WL loads each) + the next input block (HL loads) if it went out in one of the last two
+        // iterations (it is issued at tap 4, in front of that iteration's weight tile)
+        if (g + 2 < ntile) wait_vm<2 * WL + ((TAP == 5 || TAP == 6) ? HL : 0)>();
+        else if (g + 1 < ntile) wait_vm<WL>();
+        else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         if constexpr (TAP == 4) {
             if (cb + 1 < ncb) issue_halo(cb + 1, (cb + 1) & 1);       // in FRONT of this iteration's weight tile
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
             asw[i] = (j >> 2) & 3;
             aok[i] = (mask[i] >> TAP) & 1u;
         }
-        u32x4 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+        u32x4 ah[2][2], al[2][2], bh[2][WTN], bl[2][WTN];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
                 if (!aok[i]) { ah[s][i] = u32x4{0, 0, 0, 0}; al[s][i] = u32x4{0, 0, 0, 0}; }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { bh[s][j] = lds128(wt + fb_off[j][s]); bl[s][j] = lds128(wt + BP_BYTES + fb_off[j][s]); }
+            for (int j = 0; j < WTN; ++j) { bh[s][j] = lds128(wt + fb_off[j][s]); bl[s][j] = lds128(wt + BP_BYTES + fb_off[j][s]); }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -219,15 +232,15 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) Fmt::mma(al[s][i], bh[s][j], acc[i][j]);
+                for (int j = 0; j < WTN; ++j) Fmt::mma(al[s][i], bh[s][j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) Fmt::mma(ah[s][i], bl[s][j], acc[i][j]);
+                for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bl[s][j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) Fmt::mma(ah[s][i], bh[s][j], acc[i][j]);
+                for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bh[s][j], acc[i][j]);
         }
     };
     for (int cb = 0; cb < ncb; ++cb) {
@@ -248,11 +261,11 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int col = wn * 64 + j * 32 + l31;
+                const int col = wn * (32 * WTN) + j * 32 + l31;
                 stage[row * BN + col] = acc[i][j][r];
             }
     __syncthreads();
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
 }  // namespace
 
 // 3x3 / stride 1 / pad 1 split-mode argument sets this kernel takes over (checked by sq_launch_gemm_x3 after its own
-// argument validation): maps up to 31 wide, Cin a multiple of 32, N a multiple of 128, bias / ReLU epilogue only
+// argument validation): maps up to 63 wide, Cin a multiple of 32, N a multiple of 64, bias / ReLU epilogue only
 bool sq_conv_halo_x3_eligible(const GemmArgs& a) {
     if (!a.conv) return false;
     static int on = -1;
@@ -298,20 +311,30 @@ bool sq_conv_halo_x3_eligible(const GemmArgs& a) {
     }
     if (!on) return false;
     if (a.KW != 3 || a.stride != 1 || a.pad != 1 || a.H != a.OH || a.W != a.OW || a.K != 9 * a.Cin) return false;
-    if (a.Cin % CB || a.N % BN || a.W > 31 || a.W < 3 || a.ldb % 8) return false;
+    if (a.Cin % CB || a.N % 64 || a.W > 63 || a.W < 3 || a.ldb % 8) return false;
     return a.res == nullptr;
 }
 
-int sq_launch_conv_halo_x3(const GemmArgs& a, hipStream_t stream) {
+namespace {
+template <int WTN, int HROWS>
+int launch_halo(const GemmArgs& a, hipStream_t stream) {
+    using Cfg = HxCfg<WTN, HROWS>;
     static bool attr = false;
     if (!attr) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr = true;
     }
-    const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    if (a.x3_f16) hipLaunchKernelGGL(conv_halo_x3_kernel<true>, dim3(tiles), dim3(512), LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(conv_halo_x3_kernel<false>, dim3(tiles), dim3(512), LDS_BYTES, stream, a);
+    const int tiles = ((a.M + BM - 1) / BM) * (a.N / Cfg::BN);
+    if (a.x3_f16) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, true>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, false>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
+}
+}  // namespace
+
+int sq_launch_conv_halo_x3(const GemmArgs& a, hipStream_t stream) {
+    const bool wide = a.N % 128 == 0, small_map = a.W <= 31;
+    if (wide) return small_map ? launch_halo<2, 320>(a, stream) : launch_halo<2, 384>(a, stream);
+    return small_map ? launch_halo<1, 320>(a, stream) : launch_halo<1, 384>(a, stream);
 }

@@ -488,7 +488,7 @@ int sq_launch_gemm_x3(const GemmArgs& a_in, hipStream_t stream) {
     if (env_max_k < 0) { const char* e = getenv("SQ_X3_SMALL_MAXK"); env_max_k = e ? atoi(e) : 256; }
     const int small_max_k = g_x3_small_max_k >= 0 ? g_x3_small_max_k : env_max_k;
     const int rc = (g_x3_halo != 0 && sq_conv_halo_x3_eligible(a)) ? sq_launch_conv_halo_x3(a, stream)
-                 : a.K <= small_max_k ? launch_x3_fmt<128, false>(a, stream)
+                 : (a.K <= small_max_k || (a.N <= 64 && small_max_k > 0)) ? launch_x3_fmt<128, false>(a, stream)
                  : lockstep ? launch_x3_fmt<256, false>(a, stream) : launch_x3_fmt<256, true>(a, stream);
     if (prof >= 0) sq_prof_end(prof, stream);
     return rc;

@@ -142,10 +142,11 @@ def test_conv_x3_implicit_gemm(Cin, Cout, k, stride, pad, H, fmt, block_shape):
 
 @pytest.mark.parametrize("fmt", [0, 1])
 @pytest.mark.parametrize("halo", [-1, 0])
-@pytest.mark.parametrize("Cin,Cout,H,n", [(128, 128, 28, 2), (256, 256, 14, 3), (64, 128, 7, 11), (32, 256, 31, 1), (96, 128, 5, 23)])
+@pytest.mark.parametrize("Cin,Cout,H,n", [(128, 128, 28, 2), (256, 256, 14, 3), (64, 128, 7, 11), (32, 256, 31, 1), (96, 128, 5, 23),
+                                           (64, 64, 56, 1), (64, 64, 40, 2), (32, 64, 14, 3), (64, 128, 33, 1)])
 def test_conv_x3_halo_staged_3x3(Cin, Cout, H, n, halo, fmt):
     """conv_halo_x3.hip (input tile resident in LDS, all nine taps from one staged copy; taken for 3x3 / stride 1 / pad 1,
-    maps <= 31 wide, N % 128 == 0) against conv2d in fp64 on the joined operands -- image borders and image boundaries
+    maps <= 63 wide, N % 64 == 0: all four tile-width / staged-row instantiations) against conv2d in fp64 on the joined operands -- image borders and image boundaries
     inside a 256-pixel tile, a ragged last tile -- and the implicit-GEMM form (sq_dbg_set key 8 = 0) on the same problem."""
     _lib.require_gpu()
     lib = _lib.lib()
