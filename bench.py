@@ -389,27 +389,53 @@ def workload_train_kfold(args, rank, world, device):
     init = model.flat.detach().clone()
     df = pd.DataFrame(dict(patient_id=[f"P{i:05d}" for i in range(n)]))
     folds = list(zip(*patient_kfold(df, n_splits=5)))
-    # every rank materialises only its own rows (row r lives on rank r % world), already on the device
-    mine = np.arange(rank, n, world)
-    x_all = torch.from_numpy(synth.cluster_tokens(99 + rank, len(mine), 1024)).to(device)
-    y_all = torch.from_numpy(synth.rna_targets(199 + rank, len(mine), VIS_CFG["num_outputs"])).to(device)
-    pos = {int(r): i for i, r in enumerate(mine)}
+    # Every rank holds the whole synthetic cohort on its device (512 slides = 250 MB: nothing at 288 GB); a loader batch is
+    # a GLOBAL batch of per_gpu * world consecutive rows of the fold's list, of which rank r takes the r-th contiguous
+    # chunk -- so the global batches, and with them the trajectory, do not depend on the number of ranks (a ragged last
+    # batch leaves the last ranks short or empty: the exchange step handles that).
+    x_all = torch.from_numpy(synth.cluster_tokens(99, n, 1024)).to(device)
+    y_all = torch.from_numpy(synth.rna_targets(199, n, VIS_CFG["num_outputs"])).to(device)
+    gb = per_gpu * world
 
     def loader(rows):
-        sel = torch.as_tensor([pos[int(r)] for r in rows if int(r) in pos], dtype=torch.long, device=device)
-        if sel.numel() == 0:
-            return [([], [], [], [])]
-        names = [f"slide{int(r)}" for r in rows if int(r) in pos]
-        return [(x_all[sel[i:i + per_gpu]], y_all[sel[i:i + per_gpu]], names[i:i + per_gpu], ["SYN"] * len(names[i:i + per_gpu]))
-                for i in range(0, sel.numel(), per_gpu)]
+        rows = np.asarray(rows)
+        out = []
+        for b0 in range(0, len(rows), gb):
+            mine = rows[b0 + rank * per_gpu: min(b0 + (rank + 1) * per_gpu, b0 + gb, len(rows))]
+            if len(mine) == 0:
+                out.append(([], [], [], []))
+                continue
+            sel = torch.as_tensor(mine, dtype=torch.long, device=device)
+            out.append((x_all[sel], y_all[sel], [f"slide{int(r)}" for r in mine], ["SYN"] * len(mine)))
+        return out
+
+    state = {"folds_run": 0}
 
     def step():
+        state["folds_run"] = 0
         for i, (tr, va, te) in enumerate(folds):
             with torch.no_grad():
                 model.flat.copy_(init)                       # main.py:165: a new model per fold (bumps the version: bf16 shadow refreshed)
             sq_train.train(model, {"train": loader(tr), "val": loader(va)}, None, num_epochs=E, save_dir=None,
                            verbose=False, split=i, lr=1e-3)
             sq_train.evaluate(model, loader(te), verbose=False)
+            state["folds_run"] += 1
+
+    def check():
+        """After the timed region: what a reader (and tests/test_gpu_ddp.py) needs to see that the ranks did one job --
+        folds completed, the parameters of the last fold identical on every rank, their sums for a cross-run comparison."""
+        flat = model.flat.detach()
+        sums = torch.stack([flat.double().sum(), flat.double().abs().sum()])
+        same = True
+        if world > 1:
+            allp = [torch.empty_like(sums) for _ in range(world)]
+            torch.distributed.all_gather(allp, sums)
+            same = all(bool(torch.equal(a, allp[0])) for a in allp)
+        dump = os.environ.get("SQ_BENCH_DUMP_PARAMS")
+        if dump and rank == 0:
+            torch.save(flat.cpu(), dump)
+        return {"folds_run": state["folds_run"], "ranks_hold_identical_parameters": same,
+                "param_sum": float(sums[0]), "param_abs_sum": float(sums[1])}
 
     def cpu_baseline():
         from oracle import vis_oracle
@@ -428,7 +454,7 @@ def workload_train_kfold(args, rank, world, device):
         return {"value": round(rate, 3), "unit": "slides/s", "cores": threads, "kind": "port",
                 "sample": f"oracle ViS fwd+bwd+AdamW (torch-CPU fp32 autograd), {reps} steps x batch {nb}; host-side metrics not included"}
 
-    return dict(step=step, slides_per_step=per_gpu * (4 * E + 1), cpu_baseline=cpu_baseline,
+    return dict(step=step, slides_per_step=per_gpu * (4 * E + 1), cpu_baseline=cpu_baseline, check=check,
                 config={"workload": f"train_kfold: {n} synthetic slides ({per_gpu}/GPU), patient_kfold 5 folds, {E} epochs per fold "
                                     "(train + val) + test evaluation, ViS(D=1024, depth 6, 16 heads, G=20820) (BASELINE config 4)",
                         "slides": n, "epochs_per_fold": E,
@@ -553,6 +579,8 @@ def measure(name, args, rank, world, device, want_roofline=True, want_cpu=True):
     if want_cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = wl["cpu_baseline"]()
     out["_recs"] = recs
+    if wl.get("check"):
+        out["check"] = wl["check"]()
     del wl
     import gc
     gc.collect()
@@ -620,6 +648,8 @@ def main():
             "roofline": res.get("roofline"), "cpu_baseline": res.get("cpu_baseline"), "timed_region_s": res["timed_region_s"],
             "ranks": torch.distributed.get_world_size() if world > 1 else 1,
             "backend": (torch.distributed.get_backend() if world > 1 else None)}
+    if "check" in res:
+        line["check"] = res["check"]
     if args.workload == "pipeline" and args.embedder == "resnet" and rank == 0 and world == 1 and not args.no_accuracy:
         try:
             line["accuracy_vs_reference"] = accuracy_vs_reference(args.dtype, device)

@@ -262,30 +262,28 @@ class CheckpointPolicy:
         return None
 
 
-def _global_count(n_local, device):
-    """Elements of this step's batch over all ranks (ranks may hold ragged or empty batches: collate drops
-    unreadable slides).  One tiny all-reduce; every rank must call it once per step."""
-    if not _dist_on():
-        return n_local
-    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
-    dist.all_reduce(t)
-    return int(t.item())
-
-
 def _paired_batches(loader, device):
-    """Iterate a rank's loader while all ranks agree on the number of steps: a rank whose loader is exhausted (or
-    that has no loader items left) keeps yielding None until every rank is done, so collectives stay matched."""
+    """Iterate a rank's loader while all ranks agree on the number of steps, yielding (item, n_global): a rank whose loader
+    is exhausted keeps yielding None until every rank is done, so collectives stay matched.  ONE small all-reduce per step
+    carries both facts the step needs: how many ranks still have items and how many target elements the step's batch has
+    over all ranks (ranks may hold ragged or empty batches: collate drops unreadable slides)."""
     it = iter(loader)
     while True:
         item = next(it, None)
+        n_local = 0
+        if item is not None and not _is_empty(item[0]):
+            n_local = item[1].numel()
         if _dist_on():
-            alive = torch.tensor([0.0 if item is None else 1.0], device=device)
-            dist.all_reduce(alive, op=dist.ReduceOp.MAX)
-            if float(alive.item()) == 0.0:
+            t = torch.tensor([0.0 if item is None else 1.0, float(n_local)], dtype=torch.float64, device=device)
+            dist.all_reduce(t)
+            alive, n_global = (int(v) for v in t.tolist())
+            if alive == 0:
                 return
         elif item is None:
             return
-        yield item
+        else:
+            n_global = n_local
+        yield item, n_global
 
 
 def train(model, dataloaders, optimizer=None, accelerator=None,
@@ -321,16 +319,20 @@ def train(model, dataloaders, optimizer=None, accelerator=None,
             if reshuffle is not None:
                 reshuffle(epoch)                                  # DistributedSampler: a new permutation every epoch
             stats = []                                            # per batch: (loss, mae, score)
-            for batch in (_paired_batches(loader, dev) if (training and world > 1) else loader):
+            paired = training and world > 1
+            for batch in (_paired_batches(loader, dev) if paired else loader):
+                n_global = None
+                if paired:
+                    batch, n_global = batch
                 image, rna_data = (batch[0], batch[1]) if batch is not None else ([], None)
                 empty = _is_empty(image)
-                if empty and not (training and world > 1):
-                    continue                                      # vit.py:159
+                if (empty and not paired) or n_global == 0:
+                    continue                                      # vit.py:159 (under DDP: the batch is empty on EVERY rank -- no optimizer step)
                 if not empty:
                     image, rna_data = image.to(dev), rna_data.to(dev)
                 if training:
-                    n_local = 0 if empty else rna_data.numel()
-                    n_global = _global_count(n_local, dev) if world > 1 else n_local
+                    if n_global is None:
+                        n_global = rna_data.numel()
                     if fused is not None:
                         res = fused.step(None if empty else image, rna_data, n_global=n_global)
                         res = None if res is None else (res[0], res[2])
@@ -409,6 +411,9 @@ def evaluate(model, dataloader, run=None, verbose=True, suff=''):
         losses.append(float(loss))
         maes.append(float(mets[0]))
         smapes.append(smape(r_np, p_np))
+    if not preds:            # a rank whose shard of the loader is empty (slide-sharded evaluation): nothing to report
+        g = int(getattr(getattr(model, "cfg", None), "num_outputs", 0))
+        return np.zeros((0, g), np.float32), np.zeros((0, g), np.float32), np.zeros((0,), dtype=str), np.zeros((0,), dtype=str)
     losses, maes_m, smapes = np.mean(losses), np.mean(maes), np.mean(smapes)
     if run:
         run.log({'test_loss' + suff: losses})
@@ -434,4 +439,6 @@ def predict(model, dataloader, run=None, verbose=True):
         projs.append(tcga_project)
         with torch.no_grad():
             preds.append(model(image.to(dev)).cpu().numpy())
+    if not preds:
+        return np.zeros((0, int(getattr(getattr(model, "cfg", None), "num_outputs", 0))), np.float32), np.zeros((0,), dtype=str), np.zeros((0,), dtype=str)
     return np.concatenate(preds, axis=0), np.concatenate(wsis, axis=0), np.concatenate(projs, axis=0)

@@ -23,3 +23,36 @@ def test_two_rank_fused_step_equals_one_rank_step(tmp_path):
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0
     assert ok.read_text() == "ok"
+
+
+def _bench_kfold(tmp_path, gpus, batch, tag):
+    import json
+    dump = tmp_path / f"params_{tag}.pt"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SQ_BENCH_SHARE_GPU="1", SQ_BENCH_DUMP_PARAMS=str(dump))
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(gpus), "--workload", "train_kfold", "--batch", str(batch),
+           "--epochs", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(lines[-1]), dump
+
+
+def test_config4_train_kfold_two_ranks_equal_one_rank_at_the_same_global_batch(tmp_path):
+    """BASELINE config 4 (src/main.py:101-135,180-187 semantics) through bench.py itself at the model's real size
+    (ViS D = 1024, depth 6, G = 20 820, bf16): two ranks of 16 slides (shared GPU, gloo -- the multi-process control flow and
+    the bucketed exchange; RCCL is the driver's run) against ONE rank at the same global batch of 32.  Five folds run, both
+    ranks end with identical parameters, and the parameters of the last fold agree with the one-rank run."""
+    import torch
+    two, p2 = _bench_kfold(tmp_path, 2, 16, "two")
+    one, p1 = _bench_kfold(tmp_path, 1, 32, "one")
+    assert two["ranks"] == 2 and two["backend"] == "gloo" and two["n_gpus"] == 2 and one["ranks"] == 1
+    assert two["check"]["folds_run"] == 5 and one["check"]["folds_run"] == 5
+    assert two["check"]["ranks_hold_identical_parameters"] is True
+    assert two["config"]["slides"] == 32 and one["config"]["slides"] == 32
+    a, b = torch.load(p2), torch.load(p1)
+    d = (a - b).abs()
+    rel_sum = abs(two["check"]["param_abs_sum"] - one["check"]["param_abs_sum"]) / one["check"]["param_abs_sum"]
+    print(f"config 4, 2 ranks x 16 vs 1 rank x 32: param max diff {float(d.max()):.2e} mean {float(d.mean()):.2e}, abs-sum rel diff {rel_sum:.2e}; "
+          f"{two['value']:.0f} vs {one['value']:.0f} slides/s")
+    # AdamW at lr = 1e-3: a gradient whose sign differs between the two summation orders moves a parameter by up to 2 lr per step
+    assert float(d.max()) < 5e-3 and float(d.mean()) < 2e-5 and rel_sum < 1e-4

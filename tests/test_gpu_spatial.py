@@ -97,6 +97,63 @@ def test_all_gene_vote_matches_literal_loop(stride):
         assert votes.max() > 10                     # tiles in the interior belong to many windows
 
 
+def reference_loop_probe_tiles(df, feats, sd, probes, batch=16):
+    """visualize.py:35-102 at stride 1 restated for a SUBSET of tiles: every kept window that contains a probe tile goes
+    through the oracle (all genes), a probe tile's prediction is the mean over its windows (visualize.py:96-100)."""
+    max_x, max_y = max(df['xcoord_tf']), max(df['ycoord_tf'])
+    px = {k: (int(df['xcoord_tf'][k]), int(df['ycoord_tf'][k])) for k in probes}
+    wins = []
+    for x in range(0, max_x):
+        for y in range(0, max_y):
+            if not any(x <= tx < x + 10 and y <= ty < y + 10 for tx, ty in px.values()):
+                continue
+            window = df[((df['xcoord_tf'] >= x) & (df['xcoord_tf'] < (x + 10))) & ((df['ycoord_tf'] >= y) & (df['ycoord_tf'] < (y + 10)))]
+            if window.shape[0] > 50:
+                wins.append(window.index.values)
+    sums = {k: [] for k in probes}
+    for i in range(0, len(wins), batch):
+        chunk = wins[i:i + batch]
+        x = torch.zeros(len(chunk), 100, feats.shape[1])
+        for j, idx in enumerate(chunk):
+            x[j, :len(idx)] = feats[idx]
+        with torch.no_grad():
+            out = vis_oracle.vis_forward(sd, x).numpy()
+        for j, idx in enumerate(chunk):
+            for k in probes:
+                if k in idx:
+                    sums[k].append(out[j])
+    return {k: np.mean(np.stack(v), axis=0) for k, v in sums.items()}, len(wins)
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_config5_at_size_matches_literal_loop_on_probe_tiles(mode, tol):
+    """BASELINE config 5 at the model's real size (D = 1024, depth 6, 16 heads, G = 20 820) on a 40 x 30 grid, through the
+    path the bench runs: member gather inside the model's first kernel, vote before the head, one head product per tile,
+    batch_windows = 1024 -- in fp32 and in bf16 (bf16 residual stream in inference).  Checked on probe tiles (corners,
+    edges, interior: 1 ... 100 windows each) against the literal per-window loop over the oracle model."""
+    _lib.require_gpu()
+    nx, ny = 40, 30
+    xs, ys = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    df = pd.DataFrame({"xcoord_tf": xs.ravel(), "ycoord_tf": ys.ravel()})
+    feats = torch.randn(nx * ny, 1024, generator=torch.Generator().manual_seed(11))
+    cfg = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=12), seed=13)
+    m = ViS(**cfg, device="cuda:0", compute_dtype=mode)
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    out, votes = sliding_window_all_genes(df["xcoord_tf"].values, df["ycoord_tf"].values, feats.cuda(), m, 1, batch_windows=1024)
+    out, votes = out.cpu().numpy(), votes.cpu().numpy()
+    at = lambda x, y: x * ny + y
+    probes = [at(0, 0), at(39, 29), at(20, 15), at(3, 27), at(39, 4), at(12, 0)]
+    ref, n_windows = reference_loop_probe_tiles(df, feats, sd, probes)
+    assert out.shape == (nx * ny, 20820) and not np.isnan(out).any()
+    errs = {k: rel_err(out[k], ref[k]) for k in probes}
+    print(f"config 5 at size, {mode}: {n_windows} oracle windows, votes of the probe tiles {[int(votes[k]) for k in probes]}, "
+          f"worst rel err {max(errs.values()):.2e}")
+    assert votes[at(0, 0)] == 1 and votes[at(20, 15)] == 100 and votes.max() == 100
+    assert max(errs.values()) < tol, errs
+
+
 def test_visualize_cli_on_a_synthetic_slide(tmp_path):
     """spatial_vis/visualize.py:104-307 end to end: an in-memory 20x slide, mask -> valid tiles -> ResNet feature cache ->
     two-fold ViS ensemble and one HE2RNA fold -> stride-1 CSV; the CSV equals the library calls on the same cache."""
