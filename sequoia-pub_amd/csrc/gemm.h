@@ -43,9 +43,22 @@ struct GemmArgs {
     float* splitk_ws = nullptr;
     size_t splitk_ws_bytes = 0;
     int splitk = 1;                    // set by the launcher
+    // TN products only: up to 4 same-shape problems in ONE launch (grid.z = ngroup); gA / gB / gC / gcs replace A / B / C /
+    // colsum_a per member (gcs: all set or all null).  Lets independent weight gradients share a launch so that the grid
+    // fills the chip without split-K (4 x 64 tiles of a 1024 x 1024 gradient = 256 tiles)
+    int ngroup = 0;
+    const void* gA[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void* gB[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* gC[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* gcs[4] = {nullptr, nullptr, nullptr, nullptr};
     int vec_epi = 0;                   // set by sq_launch_gemm: all epilogue operands allow 16-byte accesses
     int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };
+
+// member i of a group's pointer array, i wave-uniform: selects, not an indexed load (indexing a by-value kernel argument
+// array with a run-time index makes hipcc copy the whole argument block to scratch: 520 B per lane, the kernel ran 1.5x slower)
+template <typename P>
+static __device__ __forceinline__ P sq_group_pick(P const (&a)[4], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3]; }
 
 // dtype: SQ_F32 (v_mfma_f32_32x32x2_f32, exact fp32) or SQ_BF16 (v_mfma_f32_32x32x16_bf16)
 int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream);

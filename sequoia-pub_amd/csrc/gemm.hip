@@ -461,14 +461,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             s1[0] += t1[0]; s1[1] += t1[1]; s1[2] += t1[2]; s1[3] += t1[3];
         }
         float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        epi_apply<EPI>(p, z, m, n, v, 8, vec);
+        epi_apply<EPI>(p, p.ngroup ? 0 : z, m, n, v, 8, vec, nullptr, nullptr, p.ngroup ? sq_group_pick(p.gC, z) : nullptr);     // grouped TN launch: member z has its own result pointer
     }
-    if (p.colsum_a) {              // TN products: K-slices of the bias gradient sit behind the C partials
-        const float* cs = p.splitk_ws + (size_t)p.batch * p.splitk * (size_t)p.M * p.N;
+    if (p.colsum_a) {              // TN products: K-slices of the bias gradient sit behind the C partials, [z][slice][M]
+        const float* cs = p.splitk_ws + (size_t)p.batch * p.splitk * (size_t)p.M * p.N + (size_t)z * p.splitk * p.M;
+        float* dst = p.ngroup ? sq_group_pick(p.gcs, z) : p.colsum_a;
         for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += gridDim.x * blockDim.x) {
             float s = cs[m];
             for (int k = 1; k < p.splitk; ++k) s += cs[(size_t)k * p.M + m];
-            p.colsum_a[m] = s;
+            dst[m] = s;
         }
     }
 }
@@ -588,7 +589,7 @@ extern "C" int sq_dbg_set(int key, int value) {
 int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
     const int epc = dtype == SQ_BF16 ? 8 : 4;
     SQ_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
-    SQ_REQUIRE(!a.colsum_a, "gemm: colsum_a is a TN-product feature");
+    SQ_REQUIRE(!a.colsum_a && !a.ngroup, "gemm: colsum_a / grouped launches are TN-product features");
     SQ_REQUIRE(a.K % epc == 0 && a.ldb % epc == 0, "gemm: K=%d / ldb=%d must be multiples of %d", a.K, a.ldb, epc);
     SQ_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0, "gemm: A/B must be 16-byte aligned");
     SQ_REQUIRE(a.a_bytes > 0 && a.a_bytes < (1ull << 31) && a.b_bytes > 0 && a.b_bytes < (1ull << 31),

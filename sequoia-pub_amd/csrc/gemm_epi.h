@@ -9,13 +9,14 @@
 // FAST (bf16 compute mode) takes the A&S erf
 template <int EPI, bool FAST = false>
 static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m, int n, float (&v)[8], int cnt, bool vec,
-                                          const float* pre_res = nullptr, const float* pre_bias = nullptr) {
+                                          const float* pre_res = nullptr, const float* pre_bias = nullptr, void* c_ovr = nullptr) {
     const float* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
     const float* rowbias = p.rowbias ? p.rowbias + (long long)z * p.sRb : nullptr;
     const float* res32 = (p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
     const bf16_t* res16 = (p.res && p.res_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes : nullptr;
-    float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
-    bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
+    void* const cbase = c_ovr ? c_ovr : p.C;          // c_ovr: a grouped launch's member result (z is 0 then)
+    float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(cbase) + (long long)z * p.sC : nullptr;
+    bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(cbase) + (long long)z * p.sC : nullptr;
     bf16_t* c2 = p.C2 ? p.C2 + (long long)z * p.sC2 : nullptr;
     float* cpre = (p.Cpre && p.pre_dtype == SQ_F32) ? reinterpret_cast<float*>(p.Cpre) + (long long)z * p.sPre : nullptr;
     bf16_t* cpre16 = (p.Cpre && p.pre_dtype == SQ_BF16) ? reinterpret_cast<bf16_t*>(p.Cpre) + (long long)z * p.sPre : nullptr;

@@ -76,10 +76,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
     const int n0 = cs_block ? 0 : nt * BT;
     const int z = blockIdx.z;
 
-    const T* Ab = reinterpret_cast<const T*>(p.A) + (long long)z * p.sA;
-    const T* Bb = reinterpret_cast<const T*>(p.B) + (long long)z * p.sB;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(p.a_bytes - (size_t)z * p.sA * sizeof(T)), 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(p.b_bytes - (size_t)z * p.sB * sizeof(T)), 0x00020000);
+    // grouped launch: member z brings its own operand / result pointers (same shape and leading dimensions for all)
+    const bool grouped = p.ngroup > 0;
+    const int zs = grouped ? 0 : z;                 // batch index for the strided form
+    const T* Ab = reinterpret_cast<const T*>(grouped ? sq_group_pick(p.gA, z) : p.A) + (long long)zs * p.sA;
+    const T* Bb = reinterpret_cast<const T*>(grouped ? sq_group_pick(p.gB, z) : p.B) + (long long)zs * p.sB;
+    float* const colsum_dst = grouped ? sq_group_pick(p.gcs, z) : p.colsum_a;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(p.a_bytes - (size_t)zs * p.sA * sizeof(T)), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(p.b_bytes - (size_t)zs * p.sB * sizeof(T)), 0x00020000);
 
     // DMA lane mapping: instruction j of wave w fills rows (j*4 + w) * ROWS_PER_INSTR + lane / CHUNKS
     const int lrow = lane / CHUNKS, lchunk = lane % CHUNKS;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
             }
         }
         if (wn == 0 && li == 0) {      // K-slices go behind the C partials in the split-K scratch
-            float* dst = p.splitk > 1 ? p.splitk_ws + (size_t)p.batch * p.splitk * (size_t)p.M * p.N + (size_t)blockIdx.y * p.M : p.colsum_a;
+            float* dst = p.splitk > 1 ? p.splitk_ws + (size_t)p.batch * p.splitk * (size_t)p.M * p.N + ((size_t)z * p.splitk + blockIdx.y) * p.M : colsum_dst;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BT + c8 * 8);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BT + c8 * 8 + 4);
         float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        epi_apply<3>(p, z, m, n, v, cnt, vec);
+        epi_apply<3>(p, zs, m, n, v, cnt, vec, nullptr, nullptr, grouped ? sq_group_pick(p.gC, z) : nullptr);
     }
 }
 
@@ -300,7 +304,19 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
                (a.sA % epc) == 0 && (a.sB % epc) == 0, "gemm_tn: operands must be 16-byte aligned (lda=%d ldb=%d)", a.lda, a.ldb);
     SQ_REQUIRE(a.a_bytes > 0 && a.a_bytes < (1ull << 31) && a.b_bytes > 0 && a.b_bytes < (1ull << 31), "gemm_tn: operand extents must be < 2 GiB");
     SQ_REQUIRE(!a.conv, "gemm_tn: no convolution view");
-    SQ_REQUIRE(!a.colsum_a || a.batch == 1, "gemm_tn: colsum_a needs batch == 1");
+    if (a.ngroup) {
+        SQ_REQUIRE(a.ngroup >= 1 && a.ngroup <= 4 && a.batch == 1, "gemm_tn: a group has 1..4 members and no batch (got %d, batch %d)", a.ngroup, a.batch);
+        bool any_cs = false, all_cs = true;
+        for (int i = 0; i < a.ngroup; ++i) {
+            SQ_REQUIRE(a.gA[i] && a.gB[i] && a.gC[i] && ((uintptr_t)a.gA[i] & 15) == 0 && ((uintptr_t)a.gB[i] & 15) == 0 && ((uintptr_t)a.gC[i] & 15) == 0,
+                       "gemm_tn: group member %d: null or misaligned pointer", i);
+            any_cs = any_cs || a.gcs[i]; all_cs = all_cs && a.gcs[i];
+        }
+        SQ_REQUIRE(any_cs == all_cs, "gemm_tn: bias-gradient outputs must be given for every group member or for none");
+        a.A = a.gA[0]; a.B = a.gB[0]; a.C = a.gC[0]; a.colsum_a = a.gcs[0];
+        a.batch = a.ngroup;
+    }
+    SQ_REQUIRE(!a.colsum_a || a.batch == 1 || a.ngroup, "gemm_tn: colsum_a needs batch == 1");
     {
         auto al = [](const void* ptr, int ld, long long st, int elem) {
             return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
@@ -321,10 +337,10 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
         if (s < 1) s = 1;
         if (s > nk / 2) s = nk / 2;
         if (s > 32) s = 32;
-        while (s > 1 && (size_t)s * ((size_t)a.M * a.N * a.batch + (a.colsum_a ? a.M : 0)) * sizeof(float) > a.splitk_ws_bytes) --s;
+        while (s > 1 && (size_t)s * ((size_t)a.M * a.N * a.batch + (a.colsum_a ? (size_t)a.M * a.batch : 0)) * sizeof(float) > a.splitk_ws_bytes) --s;
         if (s > 1) a.splitk = (int)s;
     }
-    if (g_tn_force_split > 0 && a.splitk_ws && (size_t)g_tn_force_split * ((size_t)a.M * a.N * a.batch + a.M) * 4 <= a.splitk_ws_bytes) a.splitk = g_tn_force_split;
+    if (g_tn_force_split > 0 && a.splitk_ws && (size_t)g_tn_force_split * ((size_t)a.M * a.N * a.batch + (size_t)a.M * a.batch) * 4 <= a.splitk_ws_bytes) a.splitk = g_tn_force_split;
     int prof = -1;
     if (sq_prof_on()) {
         const double es = dtype == SQ_BF16 ? 2.0 : 4.0;

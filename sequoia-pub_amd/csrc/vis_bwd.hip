@@ -256,6 +256,39 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         if (side) g.splitk_ws = b.skws_side;
         return sq_launch_gemm_tn(g, dtype, sst);
     };
+    // The four large weight gradients of a layer (ff2, ff1, projection, f: [1024 x 1024] each over K = B*N token rows) are
+    // independent of each other and of the dX chain.  Issued one by one each is 64 tiles of 128 x 128 -- a quarter of the
+    // chip -- so the launcher sliced K and a second launch summed the slices (37 reductions per step).  They are queued
+    // instead and leave as ONE grouped launch per layer (same-shape members share a launch: 4 x 64 = 256 tiles, whole K per
+    // tile, no partials); their operands are per-layer buffers, so nothing is overwritten in between.
+    const bool group_dw = !sq_env_flag("SQ_BWD_NO_GROUP");
+    GemmArgs pend[4];
+    int npend = 0;
+    auto queue_tn = [&](GemmArgs& g) -> int {
+        if (!group_dw) return run_tn(g);
+        pend[npend++] = g;
+        return SQ_OK;
+    };
+    auto flush_tn = [&]() -> int {
+        bool done[4] = {false, false, false, false};
+        for (int i = 0; i < npend; ++i) {
+            if (done[i]) continue;
+            GemmArgs g = pend[i];
+            g.ngroup = 0;
+            for (int j = i; j < npend; ++j) {
+                const GemmArgs& q = pend[j];
+                if (done[j] || q.M != g.M || q.N != g.N || q.K != g.K || q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc ||
+                    (q.colsum_a == nullptr) != (g.colsum_a == nullptr)) continue;
+                g.gA[g.ngroup] = q.A; g.gB[g.ngroup] = q.B; g.gC[g.ngroup] = q.C; g.gcs[g.ngroup] = q.colsum_a;
+                ++g.ngroup;
+                done[j] = true;
+            }
+            if (g.ngroup == 1) { g.ngroup = 0; }
+            if (int e = run_tn(g)) return e;
+        }
+        npend = 0;
+        return SQ_OK;
+    };
     auto bucket_done_side = [&](int i) {                          // bucket i final once the side stream gets here
         if (n_bucket_events == 0) return (int)SQ_OK;
         SQ_HIP_CHECK(hipEventRecord((hipEvent_t)bucket_events[i], sst));
@@ -273,14 +306,14 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         if (!lp) { lg.dXin_lp = dXcur; lg.dX1_lp = dXoth; }
         // ---------------- FeedForward: X2 = GELU(LN(X1) W1^T + b1) W2^T + b2 + X1 ----------------
         RUN(ready());
-        { GemmArgs g = gemm_tn(lg.dXin_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); g.colsum_a = Gp_(L.ff2_b); RUN(run_tn(g)); }
+        { GemmArgs g = gemm_tn(lg.dXin_lp, D, w.H1[l], D, Gp_(L.ff2_w), D, D, D, M); g.colsum_a = Gp_(L.ff2_b); RUN(queue_tn(g)); }
         {   // dU = (dX2 . W2) * GELU'(U)
             GemmArgs g = gemm(lg.dXin_lp, D, b.wt[l].ff2, D, nullptr, D, M, D, D);
             g.C = lg.dU; g.out_dtype = dtype; g.gelu_grad_of = w.U[l]; g.gg_dtype = sq_vis_preact_dtype(dtype); g.ldgg = D;
             RUN(sq_launch_gemm(g, dtype, st));
         }
         RUN(ready());
-        { GemmArgs g = gemm_tn(lg.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); g.colsum_a = Gp_(L.ff1_b); RUN(run_tn(g)); }
+        { GemmArgs g = gemm_tn(lg.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); g.colsum_a = Gp_(L.ff1_b); RUN(queue_tn(g)); }
         { GemmArgs g = gemm(lg.dU, D, b.wt[l].ff1, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
         // dX1 = dX2 + dLN(dY)
         RUN(sq_k_ln_rows_bwd(b.dY, w.X1[l], Pf(L.ffln_g), dXcur, dXoth, lp ? (bf16_t*)lg.dX1_lp : nullptr, Gp_(L.ffln_g),
@@ -289,7 +322,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
 
         // ---------------- projection: X1 = O Wp^T + bp + X ----------------
         RUN(ready());
-        { GemmArgs g = gemm_tn(lg.dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); g.colsum_a = Gp_(L.proj_b); RUN(run_tn(g)); }
+        { GemmArgs g = gemm_tn(lg.dX1_lp, D, w.O[l], HD, Gp_(L.proj_w), HD, D, HD, M); g.colsum_a = Gp_(L.proj_b); RUN(queue_tn(g)); }
         {   // dP = (dX1 . Wp) * GELU'(P)
             GemmArgs g = gemm(lg.dX1_lp, D, b.wt[l].proj, D, nullptr, HD, M, HD, D);
             g.C = lg.dP; g.out_dtype = dtype; g.gelu_grad_of = w.P[l]; g.gg_dtype = sq_vis_preact_dtype(dtype); g.ldgg = HD;
@@ -341,7 +374,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         }
         RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), lg.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.part_ws[2], M, HD, st, defer));
         RUN(ready());       // (the side stream has by now also waited for every summary-branch gradient of this layer)
-        { GemmArgs g = gemm_tn(lg.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(run_tn(g)); }
+        { GemmArgs g = gemm_tn(lg.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(queue_tn(g)); RUN(flush_tn()); }
         if (ev_xbar) SQ_HIP_CHECK(hipStreamWaitEvent(st, ev_xbar, 0));
         RUN(sq_k_colsum_multi(csj, st));              // needs the summary-branch partials: after the wait above
         RUN(ready());                                 // the side stream sees the layer's last gradients ...

@@ -51,6 +51,42 @@ def test_grads_match_reference_autograd(golden_dir, mode, tol):
     assert rel_err(x.grad.cpu().numpy(), xo.grad.numpy()) < tol
 
 
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_grads_with_mixed_gradient_shapes_and_grouped_launches(mode, tol, monkeypatch):
+    """nheads * 64 != input_dim: the four large weight gradients of a layer have three different shapes, so the per-layer
+    grouped launch (vis_bwd.hip: same-shape members share one TN launch) splits into a pair and two singles.  Every tensor
+    against the oracle's autograd, and the grouped path against one launch per gradient (SQ_BWD_NO_GROUP=1)."""
+    _lib.require_gpu()
+    cfg = dict(num_outputs=72, input_dim=192, depth=2, nheads=2, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=21), seed=22)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(5, 100, 192, generator=g)
+    y = torch.rand(5, 72, generator=g) * 8
+    loss_ref, _, grads_ref = vis_oracle.vis_loss_and_grads(sd, x, y)
+
+    def grads(no_group):
+        if no_group:
+            monkeypatch.setenv("SQ_BWD_NO_GROUP", "1")
+        else:
+            monkeypatch.delenv("SQ_BWD_NO_GROUP", raising=False)
+        m = ViS(**cfg, device="cuda:0", compute_dtype=mode)
+        m.load_state_dict(sd)
+        m.to("cuda:0")
+        pred = m(x.cuda())
+        loss, gpred = sq_train.mse_loss_grad(m, pred.detach(), y.cuda())
+        pred.backward(gpred)
+        torch.cuda.synchronize()
+        return m, m.flat.grad.detach().clone(), float(loss)
+    m, grouped, loss = grads(False)
+    _, single, _ = grads(True)
+    assert rel_err(grouped.cpu().numpy(), single.cpu().numpy()) < 1e-5      # same products; the K slicing (fp32 summation order) may differ
+    gv = m.grad_views(grouped)
+    worst = max(((k, rel_err(gv[k].cpu().numpy(), v.numpy())) for k, v in grads_ref.items()), key=lambda t: t[1])
+    print(f"grads (D=192, 2 heads) {mode}: worst per-tensor rel err {worst[1]:.3e} at {worst[0]}")
+    assert worst[1] < tol, worst
+    assert abs(loss - float(loss_ref)) < (1e-5 if mode == "fp32" else 2e-2) * float(loss_ref)
+
+
 def test_three_fused_adamw_steps_match_reference(golden_dir):
     _lib.require_gpu()
     z, sd, m = _tiny(golden_dir)
