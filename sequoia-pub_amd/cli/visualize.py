@@ -56,18 +56,34 @@ def valid_tiles(mask, slide_dims, patch_size_resized):
     return df
 
 
-def read_tiles(slide, df, patch_size_resized, out_size):
-    """uint8 [n, out_size, out_size, 3]: slide.read_region((col, row), 0, (p, p)) of every tile, resized (nearest for
-    equal sizes, else torch's antialiased bilinear on the device later) -- here plain area read + torch resize."""
-    tiles = np.empty((len(df), patch_size_resized, patch_size_resized, 3), dtype=np.uint8)
-    for i, (col, row) in enumerate(zip(df['xcoord'], df['ycoord'])):
+TILE_CHUNK = 512          # tiles per read -> upload -> resize -> embed round: host and device staging stay a few hundred MB
+
+
+def read_tiles(slide, df, patch_size_resized, lo=0, hi=None):
+    """uint8 [hi - lo, p, p, 3]: slide.read_region((col, row), 0, (p, p)) of tiles lo..hi-1 (visualize.py:63-66)."""
+    hi = len(df) if hi is None else hi
+    tiles = np.empty((hi - lo, patch_size_resized, patch_size_resized, 3), dtype=np.uint8)
+    for i, (col, row) in enumerate(zip(df['xcoord'][lo:hi], df['ycoord'][lo:hi])):
         r = slide.read_region((int(col), int(row)), 0, (patch_size_resized, patch_size_resized))
         tiles[i] = np.asarray(r.convert('RGB') if hasattr(r, 'convert') else r)[..., :3]
-    t = torch.from_numpy(tiles)
-    if patch_size_resized != out_size:
-        from ..uni import resize_u8
-        t = resize_u8(t, out_size)
-    return t
+    return torch.from_numpy(tiles)
+
+
+def embed_tiles(slide, df, patch_size_resized, out_size, feat_model, device, chunk=TILE_CHUNK):
+    """Feature cache [n_tiles, D] on the device: tiles go through in chunks -- read, upload, resize ON THE DEVICE
+    (antialiased bilinear, uni.resize_u8) when the read size differs from the extractor's input, embed -- so only the
+    features stay resident (a 40x slide with 50 000 valid tiles of 512 x 512 would otherwise need ~40 GB of host
+    uint8 plus the fp32 resize copies)."""
+    from ..uni import resize_u8
+    feats = []
+    for lo in range(0, len(df), chunk):
+        t = read_tiles(slide, df, patch_size_resized, lo, min(lo + chunk, len(df))).to(device)
+        if patch_size_resized != out_size:
+            t = resize_u8(t, out_size)
+        feats.append(feat_model.extract_patches_u8(t))
+    if not feats:
+        return torch.empty(0, 0, device=device)
+    return torch.cat(feats, 0)
 
 
 def open_slide(path):
@@ -137,14 +153,14 @@ def main(argv=None):
         if args.extractor_weights:
             feat_model.load_state_dict(torch.load(args.extractor_weights, map_location='cpu'))
         feat_model = feat_model.to(device).eval()
-        tile_features = feat_model.extract_patches_u8(read_tiles(slide, df, patch_size_resized, 256).to(device))
+        tile_features = embed_tiles(slide, df, patch_size_resized, 256, feat_model, device)
     else:
         from ..uni import create_model
         feat_model = create_model("vit_large_patch16_224", img_size=224, patch_size=16, init_values=1e-5, num_classes=0,
                                   dynamic_img_size=True, compute_dtype=args.compute_dtype)
         feat_model.load_state_dict(torch.load(args.extractor_weights or "./uni_ckpt/pytorch_model.bin", map_location='cpu'), strict=True)
         feat_model = feat_model.to(device).eval()
-        tile_features = feat_model.extract_patches_u8(read_tiles(slide, df, patch_size_resized, 224).to(device))
+        tile_features = embed_tiles(slide, df, patch_size_resized, 224, feat_model, device)
 
     # ---- fold ensemble (visualize.py:248-300)
     res_df = df.copy(deep=True)

@@ -152,6 +152,12 @@ class HE2RNA(nn.Module, PyTorchModelHubMixin):
             self._ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
         return self._ws
 
+    def __getstate__(self):
+        """``torch.save(model)`` (he2rna.py:261 pickles the whole module): the 64 MiB device workspace is scratch, not state."""
+        state = self.__dict__.copy()
+        state["_ws"] = None
+        return state
+
     def _run(self, x, ks, scale, training):
         _lib.require_gpu()
         if not x.is_cuda:

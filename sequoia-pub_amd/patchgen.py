@@ -105,10 +105,15 @@ class ArraySlide:
         return out
 
 
-def _resize_nearest(patch, size):
-    ys = (np.arange(size[1]) * patch.shape[0] / size[1]).astype(int)
-    xs = (np.arange(size[0]) * patch.shape[1] / size[0]).astype(int)
-    return patch[ys][:, xs]
+def _resize_like_reference(patch, size):
+    """patch_gen_hdf5.py:117 ``patch.resize(patch_size)`` on the PIL image of a 40x region: Pillow's default filter
+    (BICUBIC since Pillow 2.7; requirements.txt pins pillow==10.3.0).  Pillow is the reference's own resampler, so the
+    stored pixels are the reference's; without it there is no faithful substitute and the call fails loudly."""
+    try:
+        from PIL import Image
+    except ImportError as e:                         # pragma: no cover
+        raise RuntimeError("40x slides are shrunk with PIL.Image.resize (bicubic) as the reference does: Pillow is required") from e
+    return np.asarray(Image.fromarray(np.ascontiguousarray(patch)).resize((int(size[0]), int(size[1]))))
 
 
 def extract_patches(slide, mask_path, patch_size, patches_output_dir, slide_id, max_patches_per_slide=2000,
@@ -123,34 +128,40 @@ def extract_patches(slide, mask_path, patch_size, patches_output_dir, slide_id, 
         print(f'{slide_id}: patches have already been extreacted')
         return None
     hdf = store.File(os.path.join(patch_folder, f"{slide_id}.hdf5"), 'w')
-    mask, mask_level = get_mask(slide)
-    mask = binary_erosion(binary_dilation(mask, iterations=3), iterations=3)
-    np.save(os.path.join(mask_folder, "mask.npy"), mask)
-    ratio_x = slide.level_dimensions[0][0] / slide.level_dimensions[mask_level][0]
-    ratio_y = slide.level_dimensions[0][1] / slide.level_dimensions[mask_level][1]
-    xmax, ymax = slide.level_dimensions[0]
-    resize_factor = float(slide.properties.get('aperio.AppMag', 20)) / 20.0          # 40x slides: read 2x the size, shrink
-    size_read = (int(resize_factor * patch_size[0]), int(resize_factor * patch_size[1]))
-    print(f"patch size for {slide_id}: {size_read}")
-    indices = [(x, y) for x in range(0, xmax, size_read[0]) for y in range(0, ymax, size_read[0])]
-    if max_patches_per_slide is None:
-        max_patches_per_slide = len(indices)
-    np.random.seed(5)
-    np.random.shuffle(indices)
     n_written = 0
-    for x, y in indices:
-        if n_written >= max_patches_per_slide:
-            break
-        if mask[int(x / ratio_x), int(y / ratio_y)] != 1:
-            continue
-        patch = np.asarray(slide.read_region((x, y), 0, size_read))[:, :, :3]
-        tissue = binary_dilation(get_mask_image(patch), iterations=3)
-        if tissue.sum() > background_threshold * tissue.size and not is_low_contrast(patch):
-            if resize_factor != 1.0:
-                patch = _resize_nearest(patch, patch_size)
-            hdf.create_dataset(f"{x}_{y}", data=np.ascontiguousarray(patch))
-            n_written += 1
-    hdf.close()
+    try:          # patch_gen_hdf5.py:78,135-137: one unreadable slide prints its error and must not end the whole run
+        mask, mask_level = get_mask(slide)
+        mask = binary_erosion(binary_dilation(mask, iterations=3), iterations=3)
+        np.save(os.path.join(mask_folder, "mask.npy"), mask)
+        ratio_x = slide.level_dimensions[0][0] / slide.level_dimensions[mask_level][0]
+        ratio_y = slide.level_dimensions[0][1] / slide.level_dimensions[mask_level][1]
+        xmax, ymax = slide.level_dimensions[0]
+        resize_factor = float(slide.properties.get('aperio.AppMag', 20)) / 20.0          # 40x slides: read 2x the size, shrink
+        size_read = (int(resize_factor * patch_size[0]), int(resize_factor * patch_size[1]))
+        print(f"patch size for {slide_id}: {size_read}")
+        indices = [(x, y) for x in range(0, xmax, size_read[0]) for y in range(0, ymax, size_read[0])]
+        if max_patches_per_slide is None:
+            max_patches_per_slide = len(indices)
+        np.random.seed(5)
+        np.random.shuffle(indices)
+        for x, y in indices:
+            if n_written >= max_patches_per_slide:
+                break
+            if mask[int(x / ratio_x), int(y / ratio_y)] != 1:
+                continue
+            patch = np.asarray(slide.read_region((x, y), 0, size_read))[:, :, :3]
+            tissue = binary_dilation(get_mask_image(patch), iterations=3)
+            if tissue.sum() > background_threshold * tissue.size and not is_low_contrast(patch):
+                if resize_factor != 1.0:
+                    patch = _resize_like_reference(patch, patch_size)
+                hdf.create_dataset(f"{x}_{y}", data=np.ascontiguousarray(patch))
+                n_written += 1
+    except Exception as e:
+        print("error with slide id {} patch {}".format(slide_id, n_written))
+        print(e)
+        return None
+    finally:
+        hdf.close()
     if n_written == 0:
         print("no patch extracted for slide {}".format(slide_id))
     else:

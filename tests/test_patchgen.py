@@ -82,4 +82,27 @@ def test_40x_slides_are_read_at_double_size_and_shrunk(tmp_path):
         assert n == len(f.keys()) > 0
         for k in f.keys():
             x, y = map(int, k.split("_"))
-            assert x % 32 == 0 and y % 32 == 0 and np.asarray(f[k][:]).shape == (16, 16, 3)
+            t = np.asarray(f[k][:])
+            assert x % 32 == 0 and y % 32 == 0 and t.shape == (16, 16, 3)
+            # patch_gen_hdf5.py:117: the stored pixels are PIL's default (bicubic) resize of the 32 x 32 region
+            from PIL import Image
+            want = np.asarray(Image.fromarray(slide.levels[0][y:y + 32, x:x + 32]).resize((16, 16)))
+            assert np.array_equal(t, want)
+            assert not np.array_equal(t, slide.levels[0][y:y + 32:2, x:x + 32:2])          # (not a nearest-neighbour pick)
+
+
+def test_an_unreadable_slide_is_reported_not_raised(tmp_path, capsys):
+    """patch_gen_hdf5.py:78,135-137: the slide's body runs under try / except (one bad slide must not kill the pool's
+    map), and the patch store is closed on the way out."""
+    class Broken(patchgen.ArraySlide):
+        def read_region(self, location, level, size):
+            if level == 0:
+                raise OSError("tile decode failed")
+            return super().read_region(location, level, size)
+    good, _ = _slide(seed=3)
+    slide = Broken(good.levels)
+    assert patchgen.extract_patches(slide, str(tmp_path / "m"), (32, 32), str(tmp_path / "p"), "S3") is None
+    assert "error with slide id S3" in capsys.readouterr().out
+    assert not (tmp_path / "p" / "S3" / "complete.txt").exists()
+    with store.File(str(tmp_path / "p" / "S3" / "S3.hdf5"), "r") as f:                     # closed properly: readable, empty
+        assert len(f.keys()) == 0
