@@ -87,8 +87,8 @@ def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
     The timed region overlaps independent kernels on helper streams (weight gradients beside the dX chain, two ResNet
     chains, ...), which stretches every kernel's own start-to-end time without saying anything about the kernel.
     For the roofline the helper streams are therefore switched off during these extra steps (same kernels, same
-    shapes, one at a time); the rocprofv3 summary taken the same way is profiles/r01_*_kernel_stats_serial.csv, the one
-    of the overlapped timed region profiles/r01_*_kernel_stats.csv."""
+    shapes, one at a time); the rocprofv3 summary taken the same way is profiles/r03_*_kernel_stats_serial.csv, the one
+    of the overlapped timed region profiles/r03_*_kernel_stats.csv."""
     serial = {"SQ_BWD_ONE_STREAM": "1", "SQ_FWD_ONE_STREAM": "1", "SQ_RESNET_STREAMS": "1", "SQ_SPATIAL_STREAMS": "1"}
     saved = {k: os.environ.get(k) for k in serial}
     os.environ.update(serial)
@@ -129,7 +129,7 @@ def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
     # HBM-side bytes per launch of this kernel/shape from the committed rocprofv3 PMC passes of the same command
     # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py)
     roof["traffic_measured"] = False          # read from the committed PMC passes of the same command, not from this run
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         pmc = os.path.join(ROOT, "profiles", f"{rnd}_{workload_name}_{dtype_name}_pmc.json")
         if os.path.exists(pmc):
             cls = json.load(open(pmc)).get("classes", {}).get(dom["name"])
