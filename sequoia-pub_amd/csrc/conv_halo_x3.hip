@@ -52,7 +52,7 @@ template <int WTN, int HROWS> struct HxCfg {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WTN, int HROWS, bool F16>
+template <int WTN, int HROWS, bool F16, bool PP>
 __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
     using Fmt = X3Fmt<F16>;
     using Cfg = HxCfg<WTN, HROWS>;
@@ -176,22 +176,43 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
     // prologue: input block 0, weight tiles 0, 1, 2
     issue_halo(0, 0);
     issue_wtile(0, 0, 0);
-    issue_wtile(0, 1, 1);
-    issue_wtile(0, 2, 2);
+    if (ntile > 1) issue_wtile(0, 1, 1);
+    if (ntile > 2) issue_wtile(0, 2, 2);
 
-    auto step = [&](int cb, auto tapc) {
+    // Ping-pong schedule (as gemm_x3.hip): waves 0-3 and 4-7 -- one of each per SIMD -- run half a step apart.  A wave
+    // alternates a LOAD phase (the 16 fragment reads of step g with the border masks applied, its share of weight tile g+3
+    // and, at tap 4, of the next input block, the counted wait for everything step g+1 reads) and a MATRIX phase (24 MFMAs
+    // on registers); one block-wide barrier per phase.  Weight tile g is read in phases 2g / 2g+1 and overwritten by tile
+    // g+4, issued in phases 2g+2 / 2g+3; an input block's buffer is rewritten nine steps after its last read.
+    const int grp = PP ? wave >> 2 : 0;
+    u32x4 ah[2][2], al[2][2], bh[2][WTN], bl[2][WTN];
+    auto load_phase = [&](int cb, auto tapc) {
         constexpr int TAP = decltype(tapc)::value;
         const int g = cb * 9 + TAP;
-        // wait for weight tile g (and everything older: the input block this tap reads).  Issued after tile g's own loads:
-        // two newer weight tiles (WL loads each) + the next input block (HL loads) if it went out in one of the last two
-        // iterations (it is issued at tap 4, in front of that iteration's weight tile)
-        if (g + 2 < ntile) wait_vm<2 * WL + ((TAP == 5 || TAP == 6) ? HL : 0)>();
-        else if (g + 1 < ntile) wait_vm<WL>();
-        else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
+        const char* hb = HB + (cb & 1) * HALO_BYTES;
+        const char* wt = WR + (g & 3) * BT_BYTES;
+        const int off = (TAP / 3 - 1) * W + (TAP % 3 - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = jc[i] + off;
+            const char* arow = hb + j * ROWB;
+            const int asw = (j >> 2) & 3;
+            const bool aok = (mask[i] >> TAP) & 1u;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int co = ((2 * s + lh) ^ asw) << 4;
+                ah[s][i] = lds128(arow + co);
+                al[s][i] = lds128(arow + HP_BYTES + co);
+                if (!aok) { ah[s][i] = u32x4{0, 0, 0, 0}; al[s][i] = u32x4{0, 0, 0, 0}; }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) { bh[s][j] = lds128(wt + fb_off[j][s]); bl[s][j] = lds128(wt + BP_BYTES + fb_off[j][s]); }
         if constexpr (TAP == 4) {
-            if (cb + 1 < ncb) issue_halo(cb + 1, (cb + 1) & 1);       // in FRONT of this iteration's weight tile
-            else {                                                     // keep the per-iteration load count uniform
+            if (cb + 1 < ncb) issue_halo(cb + 1, (cb + 1) & 1);       // in FRONT of this step's weight tile
+            else {                                                     // keep the per-step load count uniform
 #pragma unroll
                 for (int u = 0; u < HL; ++u) glds16(rsAh, HB + ((cb + 1) & 1) * HALO_BYTES + u * 8192 + wave * 1024, OOB);
             }
@@ -200,32 +221,16 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
             const int g3 = g + 3;
             if (g3 < ntile) issue_wtile(g3 / 9, g3 % 9, g3 & 3);
         }
-        const char* hb = HB + (cb & 1) * HALO_BYTES;
-        const char* wt = WR + (g & 3) * BT_BYTES;
-        const int off = (TAP / 3 - 1) * W + (TAP % 3 - 1);
-        const char* arow[2];
-        int asw[2];
-        bool aok[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = jc[i] + off;
-            arow[i] = hb + j * ROWB;
-            asw[i] = (j >> 2) & 3;
-            aok[i] = (mask[i] >> TAP) & 1u;
-        }
-        u32x4 ah[2][2], al[2][2], bh[2][WTN], bl[2][WTN];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int co = ((2 * s + lh) ^ asw[i]) << 4;
-                ah[s][i] = lds128(arow[i] + co);
-                al[s][i] = lds128(arow[i] + HP_BYTES + co);
-                if (!aok[i]) { ah[s][i] = u32x4{0, 0, 0, 0}; al[s][i] = u32x4{0, 0, 0, 0}; }
-            }
-#pragma unroll
-            for (int j = 0; j < WTN; ++j) { bh[s][j] = lds128(wt + fb_off[j][s]); bl[s][j] = lds128(wt + BP_BYTES + fb_off[j][s]); }
-        }
+        // everything step g+1 reads has landed (this thread's part).  Issued after weight tile g+1: tiles g+2, g+3 and the
+        // next input block when it went out at this step or the one before (it is issued in front of its step's tile)
+        if (g + 3 < ntile) wait_vm<2 * WL + ((TAP == 4 || TAP == 5) ? HL : 0)>();
+        else if (g + 2 < ntile) wait_vm<WL>();
+        else wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto matrix_phase = [&]() {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             // the two correction terms first, the leading term last; consecutive MFMAs touch different accumulators
@@ -242,7 +247,81 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bh[s][j], acc[i][j]);
         }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
     };
+    auto step = [&](int cb, auto tapc) {
+        constexpr int TAP = decltype(tapc)::value;
+        if constexpr (PP) {
+            load_phase(cb, tapc);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            matrix_phase();
+            if (grp == 0 || cb * 9 + TAP + 1 < ntile) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // all eight waves in step, ONE barrier per step: wait for weight tile g (issued three steps ago; behind it two
+            // newer tiles and, when it went out in one of the last two steps, the next input block), then issue, read, multiply
+            const int g = cb * 9 + TAP;
+            if (g + 2 < ntile) wait_vm<2 * WL + ((TAP == 5 || TAP == 6) ? HL : 0)>();
+            else if (g + 1 < ntile) wait_vm<WL>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (TAP == 4) {
+                if (cb + 1 < ncb) issue_halo(cb + 1, (cb + 1) & 1);
+                else {
+#pragma unroll
+                    for (int u = 0; u < HL; ++u) glds16(rsAh, HB + ((cb + 1) & 1) * HALO_BYTES + u * 8192 + wave * 1024, OOB);
+                }
+            }
+            {
+                const int g3 = g + 3;
+                if (g3 < ntile) issue_wtile(g3 / 9, g3 % 9, g3 & 3);
+            }
+            const char* hb = HB + (cb & 1) * HALO_BYTES;
+            const char* wt = WR + (g & 3) * BT_BYTES;
+            const int off = (TAP / 3 - 1) * W + (TAP % 3 - 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = jc[i] + off;
+                const char* arow = hb + j * ROWB;
+                const int asw = (j >> 2) & 3;
+                const bool aok = (mask[i] >> TAP) & 1u;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int co = ((2 * s + lh) ^ asw) << 4;
+                    ah[s][i] = lds128(arow + co);
+                    al[s][i] = lds128(arow + HP_BYTES + co);
+                    if (!aok) { ah[s][i] = u32x4{0, 0, 0, 0}; al[s][i] = u32x4{0, 0, 0, 0}; }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) { bh[s][j] = lds128(wt + fb_off[j][s]); bl[s][j] = lds128(wt + BP_BYTES + fb_off[j][s]); }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) Fmt::mma(al[s][i], bh[s][j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bl[s][j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) Fmt::mma(ah[s][i], bh[s][j], acc[i][j]);
+            }
+        }
+    };
+    if constexpr (PP) {
+        // input block 0 and weight tile 0 in LDS (older than tiles 1, 2)
+        if (ntile > 2) wait_vm<2 * WL>(); else if (ntile > 1) wait_vm<WL>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 starts one phase later
+    }
     for (int cb = 0; cb < ncb; ++cb) {
         step(cb, std::integral_constant<int, 0>{});
         step(cb, std::integral_constant<int, 1>{});
@@ -321,13 +400,19 @@ int launch_halo(const GemmArgs& a, hipStream_t stream) {
     using Cfg = HxCfg<WTN, HROWS>;
     static bool attr = false;
     if (!attr) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr = true;
     }
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / Cfg::BN);
-    if (a.x3_f16) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, true>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, false>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
+    // all eight waves in step: the A/B switch, and the 64-column tile (12 MFMAs per step and wave: the load phase is the
+    // longer one and the ping-pong buys nothing -- 56 x 56 stage 478 vs 489 us)
+    static const bool lockstep_env = sq_env_flag("SQ_X3_LOCKSTEP");
+    const bool lockstep = lockstep_env || WTN == 1;
+    if (a.x3_f16 && lockstep) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, true, false>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
+    else if (a.x3_f16) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, true, true>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, false, true>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
