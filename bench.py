@@ -273,19 +273,29 @@ def workload_pipeline(args, rank, world, device):
         # copy stream, slide i+1's upload under slide i's embedding
         host = [h.pin_memory() for h in host]
         copy_stream = torch.cuda.Stream(device=device)
-        staging = [torch.empty_like(h, device=device) for h in host]
+        # two sets of staging buffers: step s uploads into set s % 2 while step s-1's slides are still being embedded; a
+        # set is free again once the step that used it two steps ago has been consumed by the main stream
+        staging = [[torch.empty_like(h, device=device) for h in host] for _ in range(2)]
+        consumed = [None, None]
+        state = {"step": 0}
 
         def step():
             main = torch.cuda.current_stream(device)
-            copy_stream.wait_stream(main)    # staging buffers of the previous step are free
+            k = state["step"] & 1
+            state["step"] += 1
+            if consumed[k] is not None:
+                copy_stream.wait_event(consumed[k])          # the main stream is done with this set's previous contents
             evs = []
             with torch.cuda.stream(copy_stream):
-                for h, d in zip(host, staging):
+                for h, d in zip(host, staging[k]):
                     d.copy_(h, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)
                     evs.append(ev)
-            run(list(zip(staging, evs)))     # the pipeline waits for slide i's upload right before embedding it
+            run(list(zip(staging[k], evs)))      # the pipeline waits for slide i's upload right before embedding it
+            done = torch.cuda.Event()
+            done.record(main)                    # (streaming form: the set's last slide may still be in flight -- see flush)
+            consumed[k] = done
     else:
         slides = [h.to(device) for h in host]
 
