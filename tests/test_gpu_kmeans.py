@@ -114,3 +114,19 @@ def test_maximum_patch_count_and_minimum():
     assert sorted(rs["labels"][0].cpu().tolist()) == list(range(100))          # every point its own cluster
     with pytest.raises(_lib.SequoiaHipError):
         kmeans_fit_batch(torch.zeros(1, 4097, 64).cuda(), 100)
+
+
+def test_slides_where_oracle_and_sklearn_part_follow_the_oracle(golden_dir):
+    """The four slides of tests/golden/kmeans_sklearn_mismatch.json (a one-ulp tie of two candidates' potentials in one
+    k-means++ step; scikit-learn's fp32 BLAS and the fl32(fp64 sum) definition pick different candidates): the HIP path
+    implements the oracle's definition, so it must take the ORACLE's centre at that step -- and scikit-learn's before it."""
+    import json
+    _lib.require_gpu()
+    fx = json.load(open(os.path.join(golden_dir, "kmeans_sklearn_mismatch.json")))
+    for m in fx["mismatches"]:
+        X = getattr(synth, "features_" + m["kind"])(m["seed"], 1000, m["dim"])
+        km = KMeans(n_clusters=100, random_state=0).fit(X)
+        first = m["first_differing_centre"]
+        assert np.array_equal(km.seed_indices_, np.array(m["oracle_indices"])), m["tag"]
+        assert np.array_equal(km.seed_indices_[:first], np.array(m["sklearn_indices"])[:first])
+        assert np.array_equal(km.labels_, ko.kmeans_fit(X)["labels"])
