@@ -1,0 +1,319 @@
+// Split-mode ("x3") chain of the 56 x 56 stage: one launch does, for a tile of 64 consecutive pixels,
+//     y   = relu(t2 . w3^T * s3 + b3 + identity)          src/resnet.py:83-91   (conv3 / bn3, += identity, relu)
+//     t1' = relu(y . w1'^T * s1' + b1')                   src/resnet.py:75-77 of the NEXT block (conv1 / bn1 / relu)
+// on hi / lo planes of 16-bit values (x3_fmt.h), three MFMAs per product.
+//
+// Why: in the split modes an activation costs 4 bytes per element, and the 56 x 56 stage's 1x1 convolutions run at what
+// the fabric gives (4.2 - 4.4 TB/s): unfused, y (1 KB per pixel) is written by the expand and read back
+// by the next block's reduce.  Here the reduce is fed from LDS: per pixel t2 (256 B) and the identity (1 KB) are read, y
+// (1 KB) and t1' (256 / 512 B) written -- 2.5 KB instead of 3.75 KB, and two launches become one.
+//
+// Tile = 64 pixels x all 256 channels, 4 waves, 80 KiB of LDS, TWO blocks per CU (one block's memory phases run under the
+// other's matrix phases):
+//   1. both 32-deep K-tiles of t2 (8 KiB) and w3 (64 KiB) arrive by LDS-DMA at once (K = 64: no ring);
+//      wave w multiplies pixels x channels [64 w, 64 w + 64): 48 MFMAs;
+//   2. the fp32 tile goes to LDS (64 KiB, over the operand buffers) in 32-byte chunks of 8 channels whose position in the
+//      1 KiB row is XOR-ed with the row index; the epilogue thread of a chunk adds bias / identity, applies ReLU, stores
+//      the y planes (512-byte runs per row and plane) and writes hi (16 B) + lo (16 B) back INTO ITS OWN 32 bytes -- the
+//      row-XOR makes exactly that image conflict-free for the A-fragment reads of the second product;
+//   3. t1' = y . w1'^T with A from LDS and the B fragments (w1', L2-resident) loaded straight into registers, four k-steps
+//      ahead, every fragment by one wave (a persistent form that keeps w1' in registers spills: 128 VGPRs beside the first
+//      product's accumulators -- measured 1.6x slower);
+//   4. t1' through a small fp32 stage (over the dead y image) -> scale / bias / ReLU -> planes.
+// Same K order, same MFMA order per accumulator and the same epilogue arithmetic as the two gemm_x3.hip launches it
+// replaces: bit-identical results (tests/test_gpu_x3.py).
+#include "gemm.h"
+#include "x3_fmt.h"
+
+#include <cstdio>
+
+namespace {
+
+constexpr uint32_t OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, uint32_t voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_base, 16, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 lds128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+constexpr int PX = 64, K1 = 64, N1 = 256;
+constexpr int A_PLANE = PX * 64;                 // one plane of one K-tile of t2: 4 KiB
+constexpr int B_PLANE = N1 * 64;                 // ... of w3: 16 KiB
+constexpr int KT_BYTES = 2 * A_PLANE + 2 * B_PLANE;    // 40 KiB
+constexpr int LDS_BYTES = 2 * KT_BYTES;          // 80 KiB (the y image needs 64 KiB of it)
+constexpr int YROW = N1 * 4;                     // 1 KiB per pixel: fp32, then 32 x [hi 16 B | lo 16 B]
+
+struct ChainX3Args {
+    const uint16_t* t2; long long plT2;          // [P, 64] planes
+    const uint16_t* w3; const uint16_t* w1n; long long plW;     // [256, 64] / [N2, 256]; lo plane plW elements behind
+    const float* b3; const float* cs3; const float* b1n; const float* cs1n;
+    const uint16_t* res; long long plRes;        // identity [P, 256]
+    uint16_t* y; long long plY;                  // [P, 256]
+    uint16_t* t1n; long long plT1n;              // [P, N2]
+    int P;
+    uint32_t t2_bytes, w3_bytes;                 // descriptor extents of one plane
+};
+
+template <int N2, bool F16>
+__global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
+    using Fmt = X3Fmt<F16>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const auto rsTh = __builtin_amdgcn_make_buffer_rsrc((void*)p.t2, 0, (int)p.t2_bytes, 0x00020000);
+    const auto rsTl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t2 + p.plT2), 0, (int)p.t2_bytes, 0x00020000);
+    const auto rsWh = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
+    const auto rsWl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w3 + p.plW), 0, (int)p.w3_bytes, 0x00020000);
+
+    // B fragments of the second product come straight from L2 into registers (w1' is 64 / 128 KiB: no room in LDS beside the
+    // y image), four k-steps per group, the next group requested while the current one is multiplied, the first one before
+    // the first epilogue.  Every wave owns one 32-column tile of t1' (N2 = 64: waves (pi, cj) = 32 pixels x tile cj;
+    // N2 = 128: wave w = all 64 pixels x tile w, so that no fragment is loaded twice).
+    // lane (n = l31, half lh) of k-step s holds k = 16 s + 8 lh .. + 8 of row n.
+    constexpr int NI2 = N2 == 64 ? 1 : 2;        // 32-pixel tiles of t1' per wave
+    const int pi = N2 == 64 ? wave >> 1 : 0, cj = N2 == 64 ? wave & 1 : wave;
+    const uint16_t* const w1src = p.w1n + (size_t)(cj * 32 + l31) * N1 + lh * 8;
+    u32x4 wbh[2][4], wbl[2][4];
+    auto load_w1 = [&](int g, int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            wbh[slot][s] = *reinterpret_cast<const u32x4*>(w1src + (g * 4 + s) * 16);
+            wbl[slot][s] = *reinterpret_cast<const u32x4*>(w1src + p.plW + (g * 4 + s) * 16);
+        }
+    };
+    const int p0 = blockIdx.x * PX;
+    // ---- 1. operands of the first product: 20 LDS-DMA instructions per thread, all in flight at once
+    {
+        const int r0 = tid >> 2, gc = (tid & 3) ^ ((r0 >> 2) & 3);
+        const int m = p0 + r0;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            char* buf = smem + kt * KT_BYTES + wave * 1024;
+            const uint32_t oa = m < p.P ? ((uint32_t)m * K1 + (uint32_t)(kt * 32 + gc * 8)) * 2u : OOB;
+            glds16(rsTh, buf, oa);
+            glds16(rsTl, buf + A_PLANE, oa);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t ob = ((uint32_t)(j * 64 + r0) * K1 + (uint32_t)(kt * 32 + gc * 8)) * 2u;
+                glds16(rsWh, buf + 2 * A_PLANE + j * 4096, ob);
+                glds16(rsWl, buf + 2 * A_PLANE + B_PLANE + j * 4096, ob);
+            }
+        }
+    }
+    // epilogue constants of this thread's 8-channel chunk
+    const int c8 = tid & 31, rsub = tid >> 5;
+    float bias8[8], scale8[8];
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b3 + c8 * 8), b1 = *reinterpret_cast<const f32x4*>(p.b3 + c8 * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; scale8[e] = 1.f; scale8[4 + e] = 1.f; }
+        if (p.cs3) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.cs3 + c8 * 8), s1 = *reinterpret_cast<const f32x4*>(p.cs3 + c8 * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { scale8[e] = s0[e]; scale8[4 + e] = s1[e]; }
+        }
+    }
+
+    // ---- first product: 64 px x channels [64 wave, +64), K = 64 -- one 32-column tile at a time (its 32 accumulator
+    // registers beside the 128 of w1'), kept in registers until every wave has read its fragments
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const char* st = smem + kt * KT_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = i * 32 + l31;
+                    const int off = row * 64 + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4);
+                    ah[i] = lds128(st + off); al[i] = lds128(st + A_PLANE + off);
+                }
+                const int rowb = wave * 64 + j * 32 + l31;
+                const int offb = 2 * A_PLANE + rowb * 64 + (((2 * s + lh) ^ ((rowb >> 2) & 3)) << 4);
+                const u32x4 bh = lds128(st + offb), bl = lds128(st + B_PLANE + offb);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) Fmt::mma(al[i], bh, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) Fmt::mma(ah[i], bl, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) Fmt::mma(ah[i], bh, acc[i][j]);
+            }
+        }
+    }
+    __syncthreads();                             // every wave has read its fragments: the buffers become the y image
+
+    // ---- 2. fp32 tile -> LDS, chunk position ^= row
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int col = wave * 64 + j * 32 + l31;
+                *reinterpret_cast<float*>(smem + row * YROW + ((((col >> 3) ^ (row & 31))) << 5) + (col & 7) * 4) = acc[i][j][r];
+            }
+    load_w1(0, 0);
+    __syncthreads();
+    // epilogue of the first product: thread = (chunk c8, rows rsub + 8 u)
+    {
+        const uint16_t* resh = p.res;
+#pragma unroll
+        for (int u0 = 0; u0 < 8; u0 += 4) {
+        u32x4 rh[4], rl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = p0 + (u0 + u) * 8 + rsub;
+            rh[u] = u32x4{0, 0, 0, 0}; rl[u] = u32x4{0, 0, 0, 0};
+            if (m < p.P) {
+                rh[u] = *reinterpret_cast<const u32x4*>(resh + (size_t)m * N1 + c8 * 8);
+                rl[u] = *reinterpret_cast<const u32x4*>(resh + p.plRes + (size_t)m * N1 + c8 * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = (u0 + u) * 8 + rsub;
+            const int m = p0 + row;
+            char* chunk = smem + row * YROW + ((c8 ^ (row & 31)) << 5);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(chunk), a1 = *reinterpret_cast<const f32x4*>(chunk + 16);
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            float idn[8];
+            x3_join8<F16>(rh[u], rl[u], idn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf((scale8[e] * v[e] + bias8[e]) + idn[e], 0.f);
+            u32x4 hi, lo;
+            x3_split8<F16>(v, hi, lo);
+            *reinterpret_cast<u32x4*>(chunk) = hi;                  // rows past P hold relu(bias): never stored, and their t1' rows neither
+            *reinterpret_cast<u32x4*>(chunk + 16) = lo;
+            if (m < p.P) {
+                *reinterpret_cast<u32x4*>(p.y + (size_t)m * N1 + c8 * 8) = hi;
+                *reinterpret_cast<u32x4*>(p.y + p.plY + (size_t)m * N1 + c8 * 8) = lo;
+            }
+        }
+        }
+    }
+    __syncthreads();                             // y image complete
+
+    // ---- 3. second product: t1'[64 px][N2], K = 256, A from the y image, B from registers
+    f32x16 acc2[NI2];
+#pragma unroll
+    for (int i = 0; i < NI2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < 3) load_w1(g + 1, (g + 1) & 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int s = g * 4 + s4;
+            u32x4 ah[NI2], al[NI2];
+#pragma unroll
+            for (int i = 0; i < NI2; ++i) {
+                const int row = (pi + i) * 32 + l31;
+                const char* cp = smem + row * YROW + (((2 * s + lh) ^ (row & 31)) << 5);     // 8-channel chunk of this lane's half of the k-step
+                ah[i] = lds128(cp); al[i] = lds128(cp + 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NI2; ++i) Fmt::mma(al[i], wbh[g & 1][s4], acc2[i]);
+#pragma unroll
+            for (int i = 0; i < NI2; ++i) Fmt::mma(ah[i], wbl[g & 1][s4], acc2[i]);
+#pragma unroll
+            for (int i = 0; i < NI2; ++i) Fmt::mma(ah[i], wbh[g & 1][s4], acc2[i]);
+        }
+    }
+    __syncthreads();                             // the y image is dead: its head becomes the t1' stage
+
+    // ---- 4. t1' = relu(acc2 * s1' + b1') -> planes
+    float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < NI2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (pi + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            stage[row * N2 + cj * 32 + l31] = acc2[i][r];
+        }
+    __syncthreads();
+    {
+        constexpr int NC = N2 / 8, RPP = 256 / NC, PASSES = PX / RPP;
+        const int e_c8 = tid % NC, e_r = tid / NC;
+        float b8[8], s8[8];
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b1n + e_c8 * 8), b1 = *reinterpret_cast<const f32x4*>(p.b1n + e_c8 * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b8[e] = b0[e]; b8[4 + e] = b1[e]; s8[e] = 1.f; s8[4 + e] = 1.f; }
+        if (p.cs1n) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.cs1n + e_c8 * 8), s1 = *reinterpret_cast<const f32x4*>(p.cs1n + e_c8 * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s8[e] = s0[e]; s8[4 + e] = s1[e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            const int row = u * RPP + e_r;
+            const int m = p0 + row;
+            if (m >= p.P) continue;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * N2 + e_c8 * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * N2 + e_c8 * 8 + 4);
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(s8[e] * v[e] + b8[e], 0.f);
+            u32x4 hi, lo;
+            x3_split8<F16>(v, hi, lo);
+            *reinterpret_cast<u32x4*>(p.t1n + (size_t)m * N2 + e_c8 * 8) = hi;
+            *reinterpret_cast<u32x4*>(p.t1n + p.plT1n + (size_t)m * N2 + e_c8 * 8) = lo;
+        }
+    }
+}
+
+}  // namespace
+
+// t2 [P, 64], res / y [P, 256], t1n [P, n2] (n2 = 64 or 128) as hi / lo planes (pl* = elements between the planes);
+// w3 [256, 64] and w1n [n2, 256] planes plW apart, biases / per-channel scales fp32 (scales may be null).
+// w3_bytes: bytes from w3 to the end of one weight plane's allocation (descriptor extent).
+int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const uint16_t* res, long long plRes, uint16_t* y, long long plY,
+                           uint16_t* t1n, long long plT1n, int n2, const uint16_t* w3, const uint16_t* w1n, long long plW, size_t w3_bytes,
+                           const float* b3, const float* cs3, const float* b1n, const float* cs1n, long long P, hipStream_t stream) {
+    SQ_REQUIRE(n2 == 64 || n2 == 128, "chain_x3: next width %d (64 or 128)", n2);
+    SQ_REQUIRE(P > 0 && P * N1 * 2 < (1ll << 31), "chain_x3: %lld pixels exceed the 2 GiB descriptor limit", P);
+    SQ_REQUIRE(t2 && res && y && t1n && w3 && w1n && b3 && b1n && w3_bytes >= (size_t)N1 * K1 * 2, "chain_x3: null pointer / weight extent");
+    ChainX3Args a;
+    a.t2 = t2; a.plT2 = plT2; a.w3 = w3; a.w1n = w1n; a.plW = plW; a.b3 = b3; a.cs3 = cs3; a.b1n = b1n; a.cs1n = cs1n;
+    a.res = res; a.plRes = plRes; a.y = y; a.plY = plY; a.t1n = t1n; a.plT1n = plT1n; a.P = (int)P;
+    a.t2_bytes = (uint32_t)(P * K1 * 2);
+    a.w3_bytes = (uint32_t)(w3_bytes < 0x7fffffffu ? w3_bytes : 0x7fffffffu);
+    static bool attr = false;
+    if (!attr) {
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr = true;
+    }
+    int prof = -1;
+    if (sq_prof_on()) {
+        char name[96];
+        snprintf(name, sizeof(name), "chain_%s_c64_cn%d_P%lld", f16 ? "f16x3" : "bf16x3", n2, P);
+        prof = sq_prof_begin(name, 2.0 * P * (64.0 * 256 + 256.0 * n2), (double)P * 4.0 * (64 + 256 + 256 + n2), stream);
+    }
+    const dim3 grid((unsigned)((P + PX - 1) / PX)), block(256);
+    if (f16) {
+        if (n2 == 64) hipLaunchKernelGGL((chain_x3_kernel<64, true>), grid, block, LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((chain_x3_kernel<128, true>), grid, block, LDS_BYTES, stream, a);
+    } else {
+        if (n2 == 64) hipLaunchKernelGGL((chain_x3_kernel<64, false>), grid, block, LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((chain_x3_kernel<128, false>), grid, block, LDS_BYTES, stream, a);
+    }
+    SQ_LAUNCH_CHECK();
+    if (prof >= 0) sq_prof_end(prof, stream);
+    return SQ_OK;
+}

@@ -103,7 +103,7 @@ def test_halo_staged_3x3_matches_implicit_gemm(monkeypatch):
     for halo in ("1", "0"):                       # the switch is read once per process
         env = dict(os.environ, SQ_CONV_HALO=halo, SQ_CONV_HALO_MIN_TILES="1")
         p = os.path.join("/tmp", f"sq_halo_{halo}_{os.getpid()}.pt")
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "halo_check.py"), p], env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "halo_check_worker.py"), p], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-800:]
         outs.append(torch.load(p))
         os.remove(p)

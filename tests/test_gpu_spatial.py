@@ -203,7 +203,7 @@ def test_visualize_cli_on_a_synthetic_slide(tmp_path):
     feat_model.load_state_dict(torch.load(rw))
     feat_model = feat_model.to("cuda:0").eval()
     df = visualize.valid_tiles(mask, (arr.shape[1], arr.shape[0]), 256)
-    tiles = visualize.read_tiles(visualize.open_slide(os.path.join(root, "TCGA", "P", "TCGA-X.npy")), df, 256, 256)
+    tiles = visualize.read_tiles(visualize.open_slide(os.path.join(root, "TCGA", "P", "TCGA-X.npy")), df, 256)
     cache = feat_model.extract_patches_u8(tiles.cuda())
     m = ViS(G, 2048, 6, 16, 64, 64, 64, device="cuda:0")
     m.load_state_dict(torch.load(os.path.join(root, "vis_resnet", "st", "model_best_1.pt")))

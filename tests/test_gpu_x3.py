@@ -208,3 +208,20 @@ def test_resnet50_x3_batch_and_stream_consistency(monkeypatch, mode):
     torch.cuda.synchronize()
     assert torch.isfinite(whole).all()
     assert torch.equal(whole, singles) and torch.equal(whole, chunks)
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x3"])
+def test_resnet50_x3_fused_chain_is_bit_identical(monkeypatch, mode):
+    """chain_x3.hip (56 x 56 stage: expand 1x1 + identity + ReLU + the next block's reduce 1x1 in one launch, y fed to the
+    second product from LDS) walks K in the same order with the same MFMA sequence and epilogue arithmetic as the two
+    gemm_x3.hip launches it replaces: the features must not change by a bit (SQ_RESNET_NO_CHAIN=1 = separate launches)."""
+    _lib.require_gpu()
+    m, sd = _model(mode)
+    p = torch.from_numpy(synth.patches_u8(5, n_patches=3, size=224)).cuda()
+    p256 = torch.from_numpy(synth.patches_u8(6, n_patches=1, size=256)).cuda()
+    fused, fused256 = m.extract_patches_u8(p), m.extract_patches_u8(p256)
+    monkeypatch.setenv("SQ_RESNET_NO_CHAIN", "1")
+    plain, plain256 = m.extract_patches_u8(p), m.extract_patches_u8(p256)
+    torch.cuda.synchronize()
+    assert torch.isfinite(fused).all()
+    assert torch.equal(fused, plain) and torch.equal(fused256, plain256)
