@@ -26,6 +26,7 @@
 #include "x3_fmt.h"
 
 #include <cstdio>
+#include <type_traits>
 
 namespace {
 
@@ -53,9 +54,15 @@ struct ChainX3Args {
     uint16_t* t1n; long long plT1n;              // [P, N2]
     int P;
     uint32_t t2_bytes, w3_bytes;                 // descriptor extents of one plane
+    // downsample form (first block of the stage): identity = xin . wd^T * sd + bd (src/resnet.py:87-88), computed here from
+    // the block's 64-channel input instead of being written and read back as a 256-channel tensor; res is unused then
+    const uint16_t* xin; long long plX;          // [P, 64]
+    const uint16_t* wd;                          // [256, 64], lo plane plW behind
+    const float* bd; const float* csd;
+    uint32_t wd_bytes;
 };
 
-template <int N2, bool F16>
+template <int N2, bool F16, bool DS>
 __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     using Fmt = X3Fmt<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,6 +74,10 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     const auto rsTl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t2 + p.plT2), 0, (int)p.t2_bytes, 0x00020000);
     const auto rsWh = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
     const auto rsWl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w3 + p.plW), 0, (int)p.w3_bytes, 0x00020000);
+    const auto rsXh = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.xin : p.t2), 0, (int)p.t2_bytes, 0x00020000);
+    const auto rsXl = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.xin + p.plX : p.t2 + p.plT2), 0, (int)p.t2_bytes, 0x00020000);
+    const auto rsDh = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.wd : p.w3), 0, (int)(DS ? p.wd_bytes : p.w3_bytes), 0x00020000);
+    const auto rsDl = __builtin_amdgcn_make_buffer_rsrc((void*)((DS ? p.wd : p.w3) + p.plW), 0, (int)(DS ? p.wd_bytes : p.w3_bytes), 0x00020000);
 
     // B fragments of the second product come straight from L2 into registers (w1' is 64 / 128 KiB: no room in LDS beside the
     // y image), four k-steps per group, the next group requested while the current one is multiplied, the first one before
@@ -85,24 +96,25 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         }
     };
     const int p0 = blockIdx.x * PX;
-    // ---- 1. operands of the first product: 20 LDS-DMA instructions per thread, all in flight at once
-    {
+    // ---- 1. operands of a 64-deep product: both K-tiles, 20 LDS-DMA instructions per thread, all in flight at once
+    auto load_operands = [&](__amdgpu_buffer_rsrc_t ah_, __amdgpu_buffer_rsrc_t al_, __amdgpu_buffer_rsrc_t bh_, __amdgpu_buffer_rsrc_t bl_) {
         const int r0 = tid >> 2, gc = (tid & 3) ^ ((r0 >> 2) & 3);
         const int m = p0 + r0;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             char* buf = smem + kt * KT_BYTES + wave * 1024;
             const uint32_t oa = m < p.P ? ((uint32_t)m * K1 + (uint32_t)(kt * 32 + gc * 8)) * 2u : OOB;
-            glds16(rsTh, buf, oa);
-            glds16(rsTl, buf + A_PLANE, oa);
+            glds16(ah_, buf, oa);
+            glds16(al_, buf + A_PLANE, oa);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t ob = ((uint32_t)(j * 64 + r0) * K1 + (uint32_t)(kt * 32 + gc * 8)) * 2u;
-                glds16(rsWh, buf + 2 * A_PLANE + j * 4096, ob);
-                glds16(rsWl, buf + 2 * A_PLANE + B_PLANE + j * 4096, ob);
+                glds16(bh_, buf + 2 * A_PLANE + j * 4096, ob);
+                glds16(bl_, buf + 2 * A_PLANE + B_PLANE + j * 4096, ob);
             }
         }
-    }
+    };
+    load_operands(rsTh, rsTl, rsWh, rsWl);
     // epilogue constants of this thread's 8-channel chunk
     const int c8 = tid & 31, rsub = tid >> 5;
     float bias8[8], scale8[8];
@@ -117,39 +129,74 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         }
     }
 
-    // ---- first product: 64 px x channels [64 wave, +64), K = 64 -- one 32-column tile at a time (its 32 accumulator
-    // registers beside the 128 of w1'), kept in registers until every wave has read its fragments
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    // ---- a 64-deep product from the staged operands: 64 px x channels [64 wave, +64), 48 MFMAs per wave
+    auto product = [&](f32x16 (&acc_)[2][2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_[i][j][e] = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const char* st = smem + kt * KT_BYTES;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                u32x4 ah[2], al[2];
+                u32x4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = i * 32 + l31;
                     const int off = row * 64 + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4);
                     ah[i] = lds128(st + off); al[i] = lds128(st + A_PLANE + off);
                 }
-                const int rowb = wave * 64 + j * 32 + l31;
-                const int offb = 2 * A_PLANE + rowb * 64 + (((2 * s + lh) ^ ((rowb >> 2) & 3)) << 4);
-                const u32x4 bh = lds128(st + offb), bl = lds128(st + B_PLANE + offb);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) Fmt::mma(al[i], bh, acc[i][j]);
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wave * 64 + j * 32 + l31;
+                    const int off = 2 * A_PLANE + row * 64 + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4);
+                    bh[j] = lds128(st + off); bl[j] = lds128(st + B_PLANE + off);
+                }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) Fmt::mma(ah[i], bl, acc[i][j]);
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) Fmt::mma(ah[i], bh, acc[i][j]);
+                    for (int j = 0; j < 2; ++j) Fmt::mma(al[i], bh[j], acc_[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Fmt::mma(ah[i], bl[j], acc_[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Fmt::mma(ah[i], bh[j], acc_[i][j]);
             }
+        }
+    };
+    f32x16 acc[2][2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    product(acc);
+    if constexpr (DS) {
+        // the downsample product through the same buffers; its result joins the first one in registers exactly as the two
+        // launches would: identity = join(split(acc_d * s_d + b_d)) (the stored planes' rounding), y = relu((acc * s3 + b3) + identity)
+        f32x16 accd[2][2];
+        __syncthreads();                         // every wave has read the first product's fragments
+        load_operands(rsXh, rsXl, rsDh, rsDl);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        product(accd);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wave * 64 + j * 32 + l31;
+            const float s3 = p.cs3 ? p.cs3[col] : 1.f, b3 = p.b3[col], sd = p.csd ? p.csd[col] : 1.f, bd = p.bd[col];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float d0 = sd * accd[i][j][r] + bd, d1 = sd * accd[i][j][r + 1] + bd;
+                    const uint32_t h = Fmt::pack2(d0, d1);
+                    const uint32_t l = Fmt::pack2(d0 - Fmt::lo_f(h), d1 - Fmt::hi_f(h));
+                    acc[i][j][r] = fmaxf((s3 * acc[i][j][r] + b3) + (Fmt::lo_f(h) + Fmt::lo_f(l)), 0.f);
+                    acc[i][j][r + 1] = fmaxf((s3 * acc[i][j][r + 1] + b3) + (Fmt::hi_f(h) + Fmt::hi_f(l)), 0.f);
+                }
         }
     }
     __syncthreads();                             // every wave has read its fragments: the buffers become the y image
@@ -177,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         for (int u = 0; u < 4; ++u) {
             const int m = p0 + (u0 + u) * 8 + rsub;
             rh[u] = u32x4{0, 0, 0, 0}; rl[u] = u32x4{0, 0, 0, 0};
-            if (m < p.P) {
+            if (!DS && m < p.P) {
                 rh[u] = *reinterpret_cast<const u32x4*>(resh + (size_t)m * N1 + c8 * 8);
                 rl[u] = *reinterpret_cast<const u32x4*>(resh + p.plRes + (size_t)m * N1 + c8 * 8);
             }
@@ -189,10 +236,12 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             char* chunk = smem + row * YROW + ((c8 ^ (row & 31)) << 5);
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(chunk), a1 = *reinterpret_cast<const f32x4*>(chunk + 16);
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            float idn[8];
-            x3_join8<F16>(rh[u], rl[u], idn);
+            if constexpr (!DS) {                 // (downsample form: the stage already holds y)
+                float idn[8];
+                x3_join8<F16>(rh[u], rl[u], idn);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf((scale8[e] * v[e] + bias8[e]) + idn[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf((scale8[e] * v[e] + bias8[e]) + idn[e], 0.f);
+            }
             u32x4 hi, lo;
             x3_split8<F16>(v, hi, lo);
             *reinterpret_cast<u32x4*>(chunk) = hi;                  // rows past P hold relu(bias): never stored, and their t1' rows neither
@@ -279,41 +328,42 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
 
 // t2 [P, 64], res / y [P, 256], t1n [P, n2] (n2 = 64 or 128) as hi / lo planes (pl* = elements between the planes);
 // w3 [256, 64] and w1n [n2, 256] planes plW apart, biases / per-channel scales fp32 (scales may be null).
-// w3_bytes: bytes from w3 to the end of one weight plane's allocation (descriptor extent).
+// Downsample form: res == nullptr, the identity is xin [P, 64] . wd^T * csd + bd (wd [256, 64], planes plW apart).
+// w3_bytes / wd_bytes: bytes from the pointer to the end of one weight plane's allocation (descriptor extent).
 int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const uint16_t* res, long long plRes, uint16_t* y, long long plY,
                            uint16_t* t1n, long long plT1n, int n2, const uint16_t* w3, const uint16_t* w1n, long long plW, size_t w3_bytes,
-                           const float* b3, const float* cs3, const float* b1n, const float* cs1n, long long P, hipStream_t stream) {
+                           const float* b3, const float* cs3, const float* b1n, const float* cs1n,
+                           const uint16_t* xin, long long plX, const uint16_t* wd, size_t wd_bytes, const float* bd, const float* csd,
+                           long long P, hipStream_t stream) {
     SQ_REQUIRE(n2 == 64 || n2 == 128, "chain_x3: next width %d (64 or 128)", n2);
     SQ_REQUIRE(P > 0 && P * N1 * 2 < (1ll << 31), "chain_x3: %lld pixels exceed the 2 GiB descriptor limit", P);
-    SQ_REQUIRE(t2 && res && y && t1n && w3 && w1n && b3 && b1n && w3_bytes >= (size_t)N1 * K1 * 2, "chain_x3: null pointer / weight extent");
+    SQ_REQUIRE(t2 && y && t1n && w3 && w1n && b3 && b1n && w3_bytes >= (size_t)N1 * K1 * 2, "chain_x3: null pointer / weight extent");
+    const bool ds = res == nullptr;
+    SQ_REQUIRE(!ds || (xin && wd && bd && wd_bytes >= (size_t)N1 * K1 * 2), "chain_x3: neither an identity tensor nor a downsample branch");
     ChainX3Args a;
     a.t2 = t2; a.plT2 = plT2; a.w3 = w3; a.w1n = w1n; a.plW = plW; a.b3 = b3; a.cs3 = cs3; a.b1n = b1n; a.cs1n = cs1n;
     a.res = res; a.plRes = plRes; a.y = y; a.plY = plY; a.t1n = t1n; a.plT1n = plT1n; a.P = (int)P;
     a.t2_bytes = (uint32_t)(P * K1 * 2);
-    a.w3_bytes = (uint32_t)(w3_bytes < 0x7fffffffu ? w3_bytes : 0x7fffffffu);
-    static bool attr = false;
-    if (!attr) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr = true;
-    }
+    auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
+    a.w3_bytes = clamp(w3_bytes);
+    a.xin = xin; a.plX = plX; a.wd = wd; a.bd = bd; a.csd = csd; a.wd_bytes = clamp(wd_bytes);
+    auto kern = [&](auto n2c, auto f16c, auto dsc) {
+        return (const void*)chain_x3_kernel<decltype(n2c)::value, decltype(f16c)::value, decltype(dsc)::value>;
+    };
+    using I64 = std::integral_constant<int, 64>; using I128 = std::integral_constant<int, 128>;
+    using T = std::true_type; using F = std::false_type;
+    const void* fn = f16 ? (n2 == 64 ? (ds ? kern(I64{}, T{}, T{}) : kern(I64{}, T{}, F{})) : (ds ? kern(I128{}, T{}, T{}) : kern(I128{}, T{}, F{})))
+                         : (n2 == 64 ? (ds ? kern(I64{}, F{}, T{}) : kern(I64{}, F{}, F{})) : (ds ? kern(I128{}, F{}, T{}) : kern(I128{}, F{}, F{})));
+    SQ_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int prof = -1;
     if (sq_prof_on()) {
         char name[96];
-        snprintf(name, sizeof(name), "chain_%s_c64_cn%d_P%lld", f16 ? "f16x3" : "bf16x3", n2, P);
-        prof = sq_prof_begin(name, 2.0 * P * (64.0 * 256 + 256.0 * n2), (double)P * 4.0 * (64 + 256 + 256 + n2), stream);
+        snprintf(name, sizeof(name), "chain_%s_c64_cn%d%s_P%lld", f16 ? "f16x3" : "bf16x3", n2, ds ? "_ds" : "", P);
+        prof = sq_prof_begin(name, 2.0 * P * (64.0 * 256 * (ds ? 2 : 1) + 256.0 * n2), (double)P * 4.0 * (64 + (ds ? 64 : 256) + 256 + n2), stream);
     }
     const dim3 grid((unsigned)((P + PX - 1) / PX)), block(256);
-    if (f16) {
-        if (n2 == 64) hipLaunchKernelGGL((chain_x3_kernel<64, true>), grid, block, LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((chain_x3_kernel<128, true>), grid, block, LDS_BYTES, stream, a);
-    } else {
-        if (n2 == 64) hipLaunchKernelGGL((chain_x3_kernel<64, false>), grid, block, LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((chain_x3_kernel<128, false>), grid, block, LDS_BYTES, stream, a);
-    }
-    SQ_LAUNCH_CHECK();
+    void* kargs[] = {(void*)&a};
+    SQ_HIP_CHECK(hipLaunchKernel(fn, grid, block, kargs, LDS_BYTES, stream));
     if (prof >= 0) sq_prof_end(prof, stream);
     return SQ_OK;
 }

@@ -31,7 +31,9 @@ int sq_launch_conv1_pool_bf16(const uint8_t* u8, const float* f32_nchw, const bf
                               int n, int S, hipStream_t stream);
 int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const uint16_t* res, long long plRes, uint16_t* y, long long plY,
                            uint16_t* t1n, long long plT1n, int n2, const uint16_t* w3, const uint16_t* w1n, long long plW, size_t w3_bytes,
-                           const float* b3, const float* cs3, const float* b1n, const float* cs1n, long long P, hipStream_t stream);
+                           const float* b3, const float* cs3, const float* b1n, const float* cs1n,
+                           const uint16_t* xin, long long plX, const uint16_t* wd, size_t wd_bytes, const float* bd, const float* csd,
+                           long long P, hipStream_t stream);
 int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, const uint16_t* w152_hi, long long w_plane, const float* bias,
                             const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream);
 
@@ -357,25 +359,32 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
             }
             void* t2 = b.act[free_[0]]; void* ds = b.act[free_[1]]; void* y = b.act[free_[2]];
             RUN(conv(c2, t1, H, t2, OH, nullptr, SQ_ACT_RELU));
-            const void* identity = x;
-            if (has_ds) {
-                RUN(conv(lay.conv[ci + 3], x, H, ds, OH, nullptr, SQ_ACT_NONE));
-                identity = ds;
-            }
             // split modes, 64-plane stage (56 x 56): expand 1x1 + identity + ReLU and the NEXT block's reduce 1x1 in one launch
-            // (chain_x3.hip): y is written once and not read back by the reduce; t1' lands in conv1's (dead) output buffer
-            if (x3 && !sq_env_flag("SQ_RESNET_NO_CHAIN") && c3.cin == 64 && c3.cout == 256 && cnext < SQ_RESNET50_CONVS && lay.conv[cnext].k == 1 &&
-                lay.conv[cnext].stride == 1 && lay.conv[cnext].cin == 256 && (lay.conv[cnext].cout == 64 || lay.conv[cnext].cout == 128)) {
+            // (chain_x3.hip): y is written once and not read back by the reduce; t1' lands in conv1's (dead) output buffer.
+            // First block: the downsample branch (64 -> 256, stride 1 here) is computed inside the launch from x.
+            if (x3 && !sq_env_flag("SQ_RESNET_NO_CHAIN") && c3.cin == 64 && c3.cout == 256 && c2.stride == 1 && cnext < SQ_RESNET50_CONVS &&
+                lay.conv[cnext].k == 1 && lay.conv[cnext].stride == 1 && lay.conv[cnext].cin == 256 &&
+                (lay.conv[cnext].cout == 64 || lay.conv[cnext].cout == 128) &&
+                (!has_ds || (lay.conv[ci + 3].k == 1 && lay.conv[ci + 3].stride == 1 && lay.conv[ci + 3].cin == 64 && !sq_env_flag("SQ_RESNET_NO_CHAIN_DS")))) {
                 const sq_conv_desc& n1 = lay.conv[cnext];
-                RUN(sq_launch_chain_x3_c64(f16, (const uint16_t*)t2, act_plane, (const uint16_t*)identity, act_plane, (uint16_t*)y, act_plane,
-                                           (uint16_t*)t1, act_plane, n1.cout, (const uint16_t*)W(c3), (const uint16_t*)W(n1), lay.w_total,
-                                           w_bytes_total - (size_t)c3.w_off * es, bias + c3.b_off, colscale + c3.b_off, bias + n1.b_off,
-                                           colscale + n1.b_off, (long long)n * OH * OH, st));
+                const sq_conv_desc& dsd = lay.conv[ci + 3];           // only read when has_ds
+                auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
+                RUN(sq_launch_chain_x3_c64(f16, (const uint16_t*)t2, act_plane, has_ds ? nullptr : (const uint16_t*)x, act_plane, (uint16_t*)y, act_plane,
+                                           (uint16_t*)t1, act_plane, n1.cout, (const uint16_t*)W(c3), (const uint16_t*)W(n1), lay.w_total, rest(c3),
+                                           bias + c3.b_off, colscale + c3.b_off, bias + n1.b_off, colscale + n1.b_off,
+                                           has_ds ? (const uint16_t*)x : nullptr, act_plane, has_ds ? (const uint16_t*)W(dsd) : nullptr,
+                                           has_ds ? rest(dsd) : 0, has_ds ? bias + dsd.b_off : nullptr, has_ds ? colscale + dsd.b_off : nullptr,
+                                           (long long)n * OH * OH, st));
                 ci = cnext;
                 xi = free_[2];
                 t1i = t1_idx;
                 H = OH;
                 continue;
+            }
+            const void* identity = x;
+            if (has_ds) {
+                RUN(conv(lay.conv[ci + 3], x, H, ds, OH, nullptr, SQ_ACT_NONE));
+                identity = ds;
             }
             // 128-plane stage (28 x 28): expand 1x1 + identity + ReLU and the NEXT block's reduce 1x1 in one launch
             // (chain.hip); its output lands in the buffer conv1's output occupied (dead once conv2 has read it)
