@@ -20,8 +20,11 @@
 //      ahead, every fragment by one wave (a persistent form that keeps w1' in registers spills: 128 VGPRs beside the first
 //      product's accumulators -- measured 1.6x slower);
 //   4. t1' through a small fp32 stage (over the dead y image) -> scale / bias / ReLU -> planes.
-// Same K order, same MFMA order per accumulator and the same epilogue arithmetic as the two gemm_x3.hip launches it
-// replaces: bit-identical results (tests/test_gpu_x3.py).
+// Tail form: the block's 3x3 convolution (64 -> 64) runs in front of step 1 on the same tile -- the 64 + 2 W + 2 input rows of
+// both 32-channel blocks resident in LDS (48 KiB), weights through a three-stage ring -- and hands t2 to the first product
+// through LDS: t2 is neither written nor read, and the 3x3's matrix work hides under the launch's memory phases.
+// Same K order, same MFMA order per accumulator and the same epilogue arithmetic as the gemm_x3.hip / conv_halo_x3.hip
+// launches it replaces: bit-identical results (tests/test_gpu_x3.py).
 #include "gemm.h"
 #include "x3_fmt.h"
 
@@ -60,9 +63,15 @@ struct ChainX3Args {
     const uint16_t* wd;                          // [256, 64], lo plane plW behind
     const float* bd; const float* csd;
     uint32_t wd_bytes;
+    // tail form: t2 is not read but computed here, t2 = relu(conv3x3(t1) * s2 + b2) (src/resnet.py:79-81), from t1 [P, 64]
+    const uint16_t* t1; long long plT1;
+    const uint16_t* w2;                          // [64, 576], k = (kh*3 + kw)*64 + cin; lo plane plW behind
+    const float* b2; const float* cs2;
+    uint32_t w2_bytes;
+    int W, HW;                                   // map width and pixels per image (square maps)
 };
 
-template <int N2, bool F16, bool DS>
+template <int N2, bool F16, bool DS, bool TAIL>
 __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     using Fmt = X3Fmt<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,15 +106,17 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     };
     const int p0 = blockIdx.x * PX;
     // ---- 1. operands of a 64-deep product: both K-tiles, 20 LDS-DMA instructions per thread, all in flight at once
-    auto load_operands = [&](__amdgpu_buffer_rsrc_t ah_, __amdgpu_buffer_rsrc_t al_, __amdgpu_buffer_rsrc_t bh_, __amdgpu_buffer_rsrc_t bl_) {
+    auto load_operands = [&](__amdgpu_buffer_rsrc_t ah_, __amdgpu_buffer_rsrc_t al_, __amdgpu_buffer_rsrc_t bh_, __amdgpu_buffer_rsrc_t bl_, bool with_a) {
         const int r0 = tid >> 2, gc = (tid & 3) ^ ((r0 >> 2) & 3);
         const int m = p0 + r0;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             char* buf = smem + kt * KT_BYTES + wave * 1024;
             const uint32_t oa = m < p.P ? ((uint32_t)m * K1 + (uint32_t)(kt * 32 + gc * 8)) * 2u : OOB;
-            glds16(ah_, buf, oa);
-            glds16(al_, buf + A_PLANE, oa);
+            if (with_a) {
+                glds16(ah_, buf, oa);
+                glds16(al_, buf + A_PLANE, oa);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t ob = ((uint32_t)(j * 64 + r0) * K1 + (uint32_t)(kt * 32 + gc * 8)) * 2u;
@@ -114,7 +125,116 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             }
         }
     };
-    load_operands(rsTh, rsTl, rsWh, rsWl);
+    if constexpr (TAIL) {
+        // ---- 0. t2 = relu(conv3x3(t1) * s2 + b2) for this tile, never leaving the CU.  The tile's 64 flat pixels need the
+        // contiguous rows [p0 - W - 1, p0 + 64 + W + 1) of t1 (<= 192 rows, W <= 62): both 32-channel blocks and both planes
+        // arrive at once (48 KiB); the weights stream as 18 tiles [64 n][32 k] x 2 planes through a three-stage ring.
+        // 4 waves = 2 (32 pixels) x 2 (32 channels), 6 MFMAs per wave and step -- the same K order (channel block, tap) and
+        // MFMA sequence as conv_halo_x3.hip.  The result goes to LDS as the A image of the first product.
+        constexpr int HROWS = 192, HPL = HROWS * 64, HCB = 2 * HPL, WST = 8192;
+        char* const HB = smem;
+        char* const WR = smem + 2 * HCB;
+        const int W = p.W;
+        const auto rs1h = __builtin_amdgcn_make_buffer_rsrc((void*)p.t1, 0, (int)p.t2_bytes, 0x00020000);
+        const auto rs1l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t1 + p.plT1), 0, (int)p.t2_bytes, 0x00020000);
+        const auto rs2h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (int)p.w2_bytes, 0x00020000);
+        const auto rs2l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w2 + p.plW), 0, (int)p.w2_bytes, 0x00020000);
+        {
+            const int halo0 = p0 - W - 1, halo_slots = (PX + 2 * W + 2) * 4;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int sl = u * 256 + tid;
+                    const int row = sl >> 2, c = (sl & 3) ^ ((row >> 2) & 3);
+                    const int px = halo0 + row;
+                    const bool ok = sl < halo_slots && px >= 0 && px < p.P;
+                    const uint32_t off = ok ? ((uint32_t)px * 64u + (uint32_t)(cb * 32 + c * 8)) * 2u : OOB;
+                    char* dst = HB + cb * HCB + u * 4096 + wave * 1024;
+                    glds16(rs1h, dst, off);
+                    glds16(rs1l, dst + HPL, off);
+                }
+        }
+        const int wn_ = tid >> 2, wc_ = (tid & 3) ^ ((wn_ >> 2) & 3);
+        auto issue_w2 = [&](int g, int stage) {
+            const int cb = g / 9, tap = g - cb * 9;
+            const uint32_t off = ((uint32_t)wn_ * 576u + (uint32_t)(tap * 64 + cb * 32 + wc_ * 8)) * 2u;
+            char* dst = WR + stage * WST + wave * 1024;
+            glds16(rs2h, dst, off);
+            glds16(rs2l, dst + 4096, off);
+        };
+        issue_w2(0, 0);
+        issue_w2(1, 1);
+        const int pi3 = wave >> 1, cj3 = wave & 1;
+        const int ml = pi3 * 32 + l31;
+        uint32_t mask = 0;
+        {
+            const int px = p0 + ml;
+            if (px < p.P) {
+                const int rem = px % p.HW, r = rem / W, c = rem - r * W, H = p.HW / W;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int rr = r + tp / 3 - 1, cc = c + tp % 3 - 1;
+                    if (rr >= 0 && rr < H && cc >= 0 && cc < W) mask |= 1u << tp;
+                }
+            }
+        }
+        const int jc = ml + W + 1;
+        const int brow = cj3 * 32 + l31;
+        f32x16 acc3;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int g = cb * 9 + tap;
+                if (g + 1 < 18) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // tile g (and the input rows) landed; tile g+1 in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const int j = jc + (tap / 3 - 1) * W + (tap % 3 - 1);
+                const char* arow = HB + cb * HCB + j * 64;
+                const int asw = (j >> 2) & 3;
+                const bool aok = (mask >> tap) & 1u;
+                const char* wt = WR + (g % 3) * WST + brow * 64;
+                const int bsw = (brow >> 2) & 3;
+                u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    ah[s2] = lds128(arow + (((2 * s2 + lh) ^ asw) << 4)); al[s2] = lds128(arow + HPL + (((2 * s2 + lh) ^ asw) << 4));
+                    if (!aok) { ah[s2] = u32x4{0, 0, 0, 0}; al[s2] = u32x4{0, 0, 0, 0}; }
+                    bh[s2] = lds128(wt + (((2 * s2 + lh) ^ bsw) << 4)); bl[s2] = lds128(wt + 4096 + (((2 * s2 + lh) ^ bsw) << 4));
+                }
+                if (g + 2 < 18) issue_w2(g + 2, (g + 2) % 3);          // behind the fragment reads: their latency covers the DMA issue
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    Fmt::mma(al[s2], bh[s2], acc3);
+                    Fmt::mma(ah[s2], bl[s2], acc3);
+                    Fmt::mma(ah[s2], bh[s2], acc3);
+                }
+            }
+        __syncthreads();                         // the input rows and the weight ring are dead
+        load_operands(rsTh, rsTl, rsWh, rsWl, false);          // w3 only: t2 comes from the registers
+        {
+            const float s2v = p.cs2 ? p.cs2[brow] : 1.f, b2v = p.b2[brow];
+            const int ck = (brow & 31) >> 3;       // K-tile of the image = channel / 32 (= cj3), 16-byte chunk ck, byte (channel & 7) * 2
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float v0 = fmaxf(s2v * acc3[r] + b2v, 0.f), v1 = fmaxf(s2v * acc3[r + 1] + b2v, 0.f);
+                const uint32_t h = Fmt::pack2(v0, v1);
+                const uint32_t l = Fmt::pack2(v0 - Fmt::lo_f(h), v1 - Fmt::hi_f(h));
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int row = pi3 * 32 + (r & 3) + e + 8 * (r >> 2) + 4 * lh;
+                    char* dst = smem + cj3 * KT_BYTES + row * 64 + ((ck ^ ((row >> 2) & 3)) << 4) + (brow & 7) * 2;
+                    *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(e ? h >> 16 : h & 0xffffu);
+                    *reinterpret_cast<uint16_t*>(dst + A_PLANE) = (uint16_t)(e ? l >> 16 : l & 0xffffu);
+                }
+            }
+        }
+    } else {
+        load_operands(rsTh, rsTl, rsWh, rsWl, true);
+    }
     // epilogue constants of this thread's 8-channel chunk
     const int c8 = tid & 31, rsub = tid >> 5;
     float bias8[8], scale8[8];
@@ -179,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         // launches would: identity = join(split(acc_d * s_d + b_d)) (the stored planes' rounding), y = relu((acc * s3 + b3) + identity)
         f32x16 accd[2][2];
         __syncthreads();                         // every wave has read the first product's fragments
-        load_operands(rsXh, rsXl, rsDh, rsDl);
+        load_operands(rsXh, rsXl, rsDh, rsDl, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         product(accd);
@@ -329,15 +449,20 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
 // t2 [P, 64], res / y [P, 256], t1n [P, n2] (n2 = 64 or 128) as hi / lo planes (pl* = elements between the planes);
 // w3 [256, 64] and w1n [n2, 256] planes plW apart, biases / per-channel scales fp32 (scales may be null).
 // Downsample form: res == nullptr, the identity is xin [P, 64] . wd^T * csd + bd (wd [256, 64], planes plW apart).
+// Tail form: t1 != nullptr -- t2 is not read but computed in the launch as relu(conv3x3(t1) * cs2 + b2) (w2 [64, 576]).
 // w3_bytes / wd_bytes: bytes from the pointer to the end of one weight plane's allocation (descriptor extent).
 int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const uint16_t* res, long long plRes, uint16_t* y, long long plY,
                            uint16_t* t1n, long long plT1n, int n2, const uint16_t* w3, const uint16_t* w1n, long long plW, size_t w3_bytes,
                            const float* b3, const float* cs3, const float* b1n, const float* cs1n,
                            const uint16_t* xin, long long plX, const uint16_t* wd, size_t wd_bytes, const float* bd, const float* csd,
+                           const uint16_t* t1, long long plT1, const uint16_t* w2, size_t w2_bytes, const float* b2, const float* cs2, int W, int HW,
                            long long P, hipStream_t stream) {
     SQ_REQUIRE(n2 == 64 || n2 == 128, "chain_x3: next width %d (64 or 128)", n2);
     SQ_REQUIRE(P > 0 && P * N1 * 2 < (1ll << 31), "chain_x3: %lld pixels exceed the 2 GiB descriptor limit", P);
-    SQ_REQUIRE(t2 && y && t1n && w3 && w1n && b3 && b1n && w3_bytes >= (size_t)N1 * K1 * 2, "chain_x3: null pointer / weight extent");
+    const bool tail = t1 != nullptr;
+    SQ_REQUIRE((t2 || tail) && y && t1n && w3 && w1n && b3 && b1n && w3_bytes >= (size_t)N1 * K1 * 2, "chain_x3: null pointer / weight extent");
+    SQ_REQUIRE(!tail || (w2 && b2 && w2_bytes >= (size_t)64 * 576 * 2 && W >= 3 && W <= 62 && HW == W * W && P % HW == 0),
+               "chain_x3: tail form needs the 3x3 weights and square maps up to 62 wide (W=%d)", W);
     const bool ds = res == nullptr;
     SQ_REQUIRE(!ds || (xin && wd && bd && wd_bytes >= (size_t)N1 * K1 * 2), "chain_x3: neither an identity tensor nor a downsample branch");
     ChainX3Args a;
@@ -347,19 +472,22 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
     a.w3_bytes = clamp(w3_bytes);
     a.xin = xin; a.plX = plX; a.wd = wd; a.bd = bd; a.csd = csd; a.wd_bytes = clamp(wd_bytes);
-    auto kern = [&](auto n2c, auto f16c, auto dsc) {
-        return (const void*)chain_x3_kernel<decltype(n2c)::value, decltype(f16c)::value, decltype(dsc)::value>;
-    };
+    a.t1 = t1; a.plT1 = plT1; a.w2 = w2; a.b2 = b2; a.cs2 = cs2; a.w2_bytes = clamp(w2_bytes); a.W = W; a.HW = HW;
     using I64 = std::integral_constant<int, 64>; using I128 = std::integral_constant<int, 128>;
     using T = std::true_type; using F = std::false_type;
-    const void* fn = f16 ? (n2 == 64 ? (ds ? kern(I64{}, T{}, T{}) : kern(I64{}, T{}, F{})) : (ds ? kern(I128{}, T{}, T{}) : kern(I128{}, T{}, F{})))
-                         : (n2 == 64 ? (ds ? kern(I64{}, F{}, T{}) : kern(I64{}, F{}, F{})) : (ds ? kern(I128{}, F{}, T{}) : kern(I128{}, F{}, F{})));
+    auto pick_tail = [&](auto n2c, auto f16c, auto dsc) {
+        return tail ? (const void*)chain_x3_kernel<decltype(n2c)::value, decltype(f16c)::value, decltype(dsc)::value, true>
+                    : (const void*)chain_x3_kernel<decltype(n2c)::value, decltype(f16c)::value, decltype(dsc)::value, false>;
+    };
+    auto pick_ds = [&](auto n2c, auto f16c) { return ds ? pick_tail(n2c, f16c, T{}) : pick_tail(n2c, f16c, F{}); };
+    auto pick_f16 = [&](auto n2c) { return f16 ? pick_ds(n2c, T{}) : pick_ds(n2c, F{}); };
+    const void* fn = n2 == 64 ? pick_f16(I64{}) : pick_f16(I128{});
     SQ_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     int prof = -1;
     if (sq_prof_on()) {
         char name[96];
-        snprintf(name, sizeof(name), "chain_%s_c64_cn%d%s_P%lld", f16 ? "f16x3" : "bf16x3", n2, ds ? "_ds" : "", P);
-        prof = sq_prof_begin(name, 2.0 * P * (64.0 * 256 * (ds ? 2 : 1) + 256.0 * n2), (double)P * 4.0 * (64 + (ds ? 64 : 256) + 256 + n2), stream);
+        snprintf(name, sizeof(name), "%s_%s_c64_cn%d%s_P%lld", tail ? "tail" : "chain", f16 ? "f16x3" : "bf16x3", n2, ds ? "_ds" : "", P);
+        prof = sq_prof_begin(name, 2.0 * P * ((tail ? 576.0 * 64 : 0.0) + 64.0 * 256 * (ds ? 2 : 1) + 256.0 * n2), (double)P * 4.0 * (64 + (ds ? 64 : 256) + 256 + n2), stream);
     }
     const dim3 grid((unsigned)((P + PX - 1) / PX)), block(256);
     void* kargs[] = {(void*)&a};

@@ -33,6 +33,7 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
                            uint16_t* t1n, long long plT1n, int n2, const uint16_t* w3, const uint16_t* w1n, long long plW, size_t w3_bytes,
                            const float* b3, const float* cs3, const float* b1n, const float* cs1n,
                            const uint16_t* xin, long long plX, const uint16_t* wd, size_t wd_bytes, const float* bd, const float* csd,
+                           const uint16_t* t1, long long plT1, const uint16_t* w2, size_t w2_bytes, const float* b2, const float* cs2, int W, int HW,
                            long long P, hipStream_t stream);
 int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, const uint16_t* w152_hi, long long w_plane, const float* bias,
                             const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream);
@@ -358,26 +359,33 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                 continue;
             }
             void* t2 = b.act[free_[0]]; void* ds = b.act[free_[1]]; void* y = b.act[free_[2]];
-            RUN(conv(c2, t1, H, t2, OH, nullptr, SQ_ACT_RELU));
-            // split modes, 64-plane stage (56 x 56): expand 1x1 + identity + ReLU and the NEXT block's reduce 1x1 in one launch
-            // (chain_x3.hip): y is written once and not read back by the reduce; t1' lands in conv1's (dead) output buffer.
-            // First block: the downsample branch (64 -> 256, stride 1 here) is computed inside the launch from x.
-            if (x3 && !sq_env_flag("SQ_RESNET_NO_CHAIN") && c3.cin == 64 && c3.cout == 256 && c2.stride == 1 && cnext < SQ_RESNET50_CONVS &&
-                lay.conv[cnext].k == 1 && lay.conv[cnext].stride == 1 && lay.conv[cnext].cin == 256 &&
+            // split modes, 64-plane stage (56 x 56): 3x3 + expand 1x1 + identity + ReLU and the NEXT block's reduce 1x1 in one
+            // launch (chain_x3.hip, tail form; SQ_RESNET_NO_TAIL=1: the 3x3 as its own launch, SQ_RESNET_NO_CHAIN=1: nothing
+            // fused): t2 never leaves the CU, y is written once and not read back by the reduce; t1' lands in the buffer of
+            // the other narrow tensor.  First block: the downsample branch (64 -> 256, stride 1 here) is computed inside too.
+            const bool x3_chain = x3 && !sq_env_flag("SQ_RESNET_NO_CHAIN") && c3.cin == 64 && c3.cout == 256 && c2.stride == 1 &&
+                cnext < SQ_RESNET50_CONVS && lay.conv[cnext].k == 1 && lay.conv[cnext].stride == 1 && lay.conv[cnext].cin == 256 &&
                 (lay.conv[cnext].cout == 64 || lay.conv[cnext].cout == 128) &&
-                (!has_ds || (lay.conv[ci + 3].k == 1 && lay.conv[ci + 3].stride == 1 && lay.conv[ci + 3].cin == 64 && !sq_env_flag("SQ_RESNET_NO_CHAIN_DS")))) {
+                (!has_ds || (lay.conv[ci + 3].k == 1 && lay.conv[ci + 3].stride == 1 && lay.conv[ci + 3].cin == 64 && !sq_env_flag("SQ_RESNET_NO_CHAIN_DS")));
+            const bool x3_tail = x3_chain && c2.k == 3 && c2.cin == 64 && c2.cout == 64 && H <= 62 && !sq_env_flag("SQ_RESNET_NO_TAIL");
+            if (!x3_tail) RUN(conv(c2, t1, H, t2, OH, nullptr, SQ_ACT_RELU));
+            if (x3_chain) {
                 const sq_conv_desc& n1 = lay.conv[cnext];
                 const sq_conv_desc& dsd = lay.conv[ci + 3];           // only read when has_ds
                 auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
-                RUN(sq_launch_chain_x3_c64(f16, (const uint16_t*)t2, act_plane, has_ds ? nullptr : (const uint16_t*)x, act_plane, (uint16_t*)y, act_plane,
-                                           (uint16_t*)t1, act_plane, n1.cout, (const uint16_t*)W(c3), (const uint16_t*)W(n1), lay.w_total, rest(c3),
-                                           bias + c3.b_off, colscale + c3.b_off, bias + n1.b_off, colscale + n1.b_off,
+                // t1' goes where no input of this launch lives: conv1's buffer when the 3x3 ran separately, else the t2 buffer
+                void* t1n = x3_tail ? t2 : t1;
+                RUN(sq_launch_chain_x3_c64(f16, x3_tail ? nullptr : (const uint16_t*)t2, act_plane, has_ds ? nullptr : (const uint16_t*)x, act_plane,
+                                           (uint16_t*)y, act_plane, (uint16_t*)t1n, act_plane, n1.cout, (const uint16_t*)W(c3), (const uint16_t*)W(n1),
+                                           lay.w_total, rest(c3), bias + c3.b_off, colscale + c3.b_off, bias + n1.b_off, colscale + n1.b_off,
                                            has_ds ? (const uint16_t*)x : nullptr, act_plane, has_ds ? (const uint16_t*)W(dsd) : nullptr,
                                            has_ds ? rest(dsd) : 0, has_ds ? bias + dsd.b_off : nullptr, has_ds ? colscale + dsd.b_off : nullptr,
+                                           x3_tail ? (const uint16_t*)t1 : nullptr, act_plane, x3_tail ? (const uint16_t*)W(c2) : nullptr,
+                                           x3_tail ? rest(c2) : 0, x3_tail ? bias + c2.b_off : nullptr, x3_tail ? colscale + c2.b_off : nullptr, H, H * H,
                                            (long long)n * OH * OH, st));
                 ci = cnext;
                 xi = free_[2];
-                t1i = t1_idx;
+                t1i = x3_tail ? free_[0] : t1_idx;
                 H = OH;
                 continue;
             }

@@ -212,16 +212,24 @@ def test_resnet50_x3_batch_and_stream_consistency(monkeypatch, mode):
 
 @pytest.mark.parametrize("mode", ["f16x3", "bf16x3"])
 def test_resnet50_x3_fused_chain_is_bit_identical(monkeypatch, mode):
-    """chain_x3.hip (56 x 56 stage: expand 1x1 + identity + ReLU + the next block's reduce 1x1 in one launch, y fed to the
-    second product from LDS) walks K in the same order with the same MFMA sequence and epilogue arithmetic as the two
-    gemm_x3.hip launches it replaces: the features must not change by a bit (SQ_RESNET_NO_CHAIN=1 = separate launches)."""
+    """chain_x3.hip (56 x 56 stage: [3x3 +] expand 1x1 + identity [or the downsample product] + ReLU + the next block's reduce
+    1x1 in one launch, t2 and y handed over through LDS) walks K in the same order with the same MFMA sequence and epilogue
+    arithmetic as the gemm_x3.hip / conv_halo_x3.hip launches it replaces: the features must not change by a bit.
+    SQ_RESNET_NO_TAIL=1: the 3x3 as its own launch; SQ_RESNET_NO_CHAIN_DS=1: the downsample branch too; SQ_RESNET_NO_CHAIN=1:
+    nothing fused."""
     _lib.require_gpu()
     m, sd = _model(mode)
     p = torch.from_numpy(synth.patches_u8(5, n_patches=3, size=224)).cuda()
-    p256 = torch.from_numpy(synth.patches_u8(6, n_patches=1, size=256)).cuda()
-    fused, fused256 = m.extract_patches_u8(p), m.extract_patches_u8(p256)
-    monkeypatch.setenv("SQ_RESNET_NO_CHAIN", "1")
-    plain, plain256 = m.extract_patches_u8(p), m.extract_patches_u8(p256)
+    p256 = torch.from_numpy(synth.patches_u8(6, n_patches=1, size=256)).cuda()          # 64 x 64 maps: wider than the tail form takes
+    outs = {}
+    for tag, env in (("tail", {}), ("chain", {"SQ_RESNET_NO_TAIL": "1"}), ("chain_no_ds", {"SQ_RESNET_NO_TAIL": "1", "SQ_RESNET_NO_CHAIN_DS": "1"}),
+                     ("plain", {"SQ_RESNET_NO_CHAIN": "1"})):
+        for k in ("SQ_RESNET_NO_TAIL", "SQ_RESNET_NO_CHAIN_DS", "SQ_RESNET_NO_CHAIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[tag] = (m.extract_patches_u8(p), m.extract_patches_u8(p256))
     torch.cuda.synchronize()
-    assert torch.isfinite(fused).all()
-    assert torch.equal(fused, plain) and torch.equal(fused256, plain256)
+    assert torch.isfinite(outs["tail"][0]).all()
+    for tag in ("tail", "chain", "chain_no_ds"):
+        assert torch.equal(outs[tag][0], outs["plain"][0]) and torch.equal(outs[tag][1], outs["plain"][1]), tag
