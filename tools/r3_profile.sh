@@ -23,15 +23,15 @@ for w in pipe pipe_serial train train_serial; do
   [ -n "$f" ] && cp $f gpurun_out/profiles_r03/$t
 done
 python tools/pmc_summary.py r03_pipeline_f16x3 gpurun_out/profiles_r03/r03_pipeline_f16x3_pmc.json $O/pmc_pipe_FETCH_SIZE $O/pmc_pipe_WRITE_SIZE $O/pmc_pipe_SQ_VALU_MFMA_BUSY_CYCLES \
-  "gemm_f16x3_M1568000_N256_K64=gemm_x3_kernel<128, 2, false, true, false>:6272000" \
   "gemm_f16x3_M98000_N1024_K256=gemm_x3_kernel<128, 2, false, true, false>:1568768" \
   "gemm_f16x3_M392000_N512_K128=gemm_x3_kernel<128, 2, false, true, false>:3136512" \
-  "gemm_f16x3_M1568000_N64_K256=gemm_x3_kernel<128, 1, false, true, false>:3136000" \
   "gemm_f16x3_M98000_N256_K1024=gemm_x3_kernel<256, 2, false, true, true>:392192" \
-  "conv_f16x3_M98000_N256_K2304=conv_halo_x3_kernel<2, 320, true>:392192" \
-  "conv_f16x3_M392000_N128_K1152=conv_halo_x3_kernel<2, 320, true>:784384" \
-  "conv_f16x3_M24500_N512_K4608=conv_halo_x3_kernel<2, 320, true>:196608" \
-  "conv_f16x3_M1568000_N64_K576=conv_halo_x3_kernel<1, 384, true>:3136000" \
+  "conv_f16x3_M98000_N256_K2304=conv_halo_x3_kernel<2, 320, true, true>:392192" \
+  "conv_f16x3_M392000_N128_K1152=conv_halo_x3_kernel<2, 320, true, true>:784384" \
+  "conv_f16x3_M24500_N512_K4608=conv_halo_x3_kernel<2, 320, true, true>:196608" \
+  "tail_f16x3_c64_cn64_P1568000=chain_x3_kernel<64, true, false, true>:6272000" \
+  "tail_f16x3_c64_cn64_ds_P1568000=chain_x3_kernel<64, true, true, true>:6272000" \
+  "tail_f16x3_c64_cn128_P1568000=chain_x3_kernel<128, true, false, true>:6272000" \
   "conv1_pool_f16x3=conv1_pool_x3_kernel<true>:131072"
 python tools/pmc_summary.py r03_vis_train_bf16 gpurun_out/profiles_r03/r03_vis_train_bf16_pmc.json $O/pmc_train_FETCH_SIZE $O/pmc_train_WRITE_SIZE $O/pmc_train_SQ_VALU_MFMA_BUSY_CYCLES \
   "gemm_bf16_M6400_N1024_K1024_b1=gemm_nt_kernel<unsigned short, 2, 2, false:102400" \
@@ -45,7 +45,7 @@ for f in glob.glob('gpurun_out/prof_r03/pmc_pipe_SQ/**/*counter_collection.csv',
         acc[n + "|grid=" + r['Grid_Size']][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {}
 for k, cs in acc.items():
-    if 'x3' not in k: continue
+    if 'x3' not in k and 'chain' not in k: continue
     c = {n: sum(v) / len(v) for n, v in cs.items()}
     wc = c.get('SQ_WAVE_CYCLES', 1.0)
     out[k] = {"dispatches": len(next(iter(cs.values()))), "SQ_WAVE_CYCLES": round(wc),
@@ -55,6 +55,7 @@ json.dump({"note": "SQ counters as fractions of SQ_WAVE_CYCLES per kernel symbol
 print("sq kernels", len(out))
 PY
 SQ_BENCH_KERNELS=gpurun_out/profiles_r03/r03_pipeline_f16x3_bench_kernels.json python bench.py --no-secondary --no-cpu-baseline --no-accuracy > gpurun_out/profiles_r03/r03_pipeline_f16x3_bench_line.json 2>/dev/null
+python bench.py > gpurun_out/profiles_r03/r03_bench_final.json 2>/dev/null
 SQ_BENCH_KERNELS=gpurun_out/profiles_r03/r03_vis_train_bf16_bench_kernels.json python bench.py --workload vis_train --no-secondary --no-cpu-baseline > gpurun_out/profiles_r03/r03_vis_train_bf16_bench_line.json 2>/dev/null
 ls -la gpurun_out/profiles_r03
 find $O -name "*.csv" -size +5M -delete
