@@ -31,6 +31,8 @@
 #include <cstdio>
 #include <type_traits>
 
+extern int g_dbg;                // sq_dbg_set key 1 (gemm.hip)
+
 namespace {
 
 constexpr uint32_t OOB = 0x80000000u;
@@ -40,6 +42,22 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ba
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_base, 16, voffset, 0, 0, 0);
 }
 __device__ __forceinline__ u32x4 lds128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// n is a constant after unrolling: the switch folds to one s_waitcnt
+__device__ __forceinline__ void wait_vm_n(int n) {
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 2: wait_vm<2>(); break;
+        case 4: wait_vm<4>(); break;
+        case 6: wait_vm<6>(); break;
+        case 8: wait_vm<8>(); break;
+        case 10: wait_vm<10>(); break;
+        case 12: wait_vm<12>(); break;
+        case 14: wait_vm<14>(); break;
+        case 16: wait_vm<16>(); break;
+        default: wait_vm<0>(); break;
+    }
+}
 
 constexpr int PX = 64, K1 = 64, N1 = 256;
 constexpr int A_PLANE = PX * 64;                 // one plane of one K-tile of t2: 4 KiB
@@ -69,6 +87,7 @@ struct ChainX3Args {
     const float* b2; const float* cs2;
     uint32_t w2_bytes;
     int W, HW;                                   // map width and pixels per image (square maps)
+    int dbg;                                     // ablation switches (tools/chain_probe.py): 1 no stores, 2 no identity reads, 4 no 3x3, 8 no second product
 };
 
 template <int N2, bool F16, bool DS, bool TAIL>
@@ -81,12 +100,8 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
 
     const auto rsTh = __builtin_amdgcn_make_buffer_rsrc((void*)p.t2, 0, (int)p.t2_bytes, 0x00020000);
     const auto rsTl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.t2 + p.plT2), 0, (int)p.t2_bytes, 0x00020000);
-    const auto rsWh = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
-    const auto rsWl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w3 + p.plW), 0, (int)p.w3_bytes, 0x00020000);
     const auto rsXh = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.xin : p.t2), 0, (int)p.t2_bytes, 0x00020000);
     const auto rsXl = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.xin + p.plX : p.t2 + p.plT2), 0, (int)p.t2_bytes, 0x00020000);
-    const auto rsDh = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? p.wd : p.w3), 0, (int)(DS ? p.wd_bytes : p.w3_bytes), 0x00020000);
-    const auto rsDl = __builtin_amdgcn_make_buffer_rsrc((void*)((DS ? p.wd : p.w3) + p.plW), 0, (int)(DS ? p.wd_bytes : p.w3_bytes), 0x00020000);
 
     // B fragments of the second product come straight from L2 into registers (w1' is 64 / 128 KiB: no room in LDS beside the
     // y image), four k-steps per group, the next group requested while the current one is multiplied, the first one before
@@ -95,40 +110,64 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     // lane (n = l31, half lh) of k-step s holds k = 16 s + 8 lh .. + 8 of row n.
     constexpr int NI2 = N2 == 64 ? 1 : 2;        // 32-pixel tiles of t1' per wave
     const int pi = N2 == 64 ? wave >> 1 : 0, cj = N2 == 64 ? wave & 1 : wave;
-    const uint16_t* const w1src = p.w1n + (size_t)(cj * 32 + l31) * N1 + lh * 8;
-    u32x4 wbh[2][4], wbl[2][4];
+    const uint16_t* const w1src = p.w1n + (size_t)cj * 16 * 512 + lane * 8;      // fragment order: 1 KiB per (column tile, k-step)
+    constexpr int W1PRE = DS ? 4 : 3;            // groups of w1' (of 4) requested before the first epilogue; the rest when the identity registers are free
+    u32x4 wbh[4][4], wbl[4][4];
     auto load_w1 = [&](int g, int slot) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            wbh[slot][s] = *reinterpret_cast<const u32x4*>(w1src + (g * 4 + s) * 16);
-            wbl[slot][s] = *reinterpret_cast<const u32x4*>(w1src + p.plW + (g * 4 + s) * 16);
+            wbh[slot][s] = *reinterpret_cast<const u32x4*>(w1src + (g * 4 + s) * 512);
+            wbl[slot][s] = *reinterpret_cast<const u32x4*>(w1src + p.plW + (g * 4 + s) * 512);
         }
     };
     const int p0 = blockIdx.x * PX;
-    // ---- 1. operands of a 64-deep product: both K-tiles, 20 LDS-DMA instructions per thread, all in flight at once
-    auto load_operands = [&](__amdgpu_buffer_rsrc_t ah_, __amdgpu_buffer_rsrc_t al_, __amdgpu_buffer_rsrc_t bh_, __amdgpu_buffer_rsrc_t bl_, bool with_a) {
+    // ---- the launch's long-latency reads are requested before anything else and land while the 3x3 runs:
+    // (a) the B fragments of the 64-deep products.  Wave w multiplies all 64 pixels by channels [64 w, 64 w + 64): no other
+    //     wave reads those rows of w3 / wd, so they go straight from L2 into registers (lane (n = l31, half lh) of k-step ks
+    //     holds k = 16 ks + 8 lh .. + 8 of row 64 w + 32 j + n) instead of through LDS;
+    // (b) the identity rows of this thread's eight epilogue chunks (1 KiB per pixel, the launch's largest HBM read).
+    // In the tail form these 32 reads are dealt four at a time behind the first eight steps of the 3x3 (vmcnt retires in
+    // order: requested in front of the input rows they would hold up the first step, requested at the end nothing hides them).
+    u32x4 w3h[2][4], w3l[2][4], wdh[2][4], wdl[2][4];
+    auto load_wfrag = [&](const uint16_t* w, u32x4 (&h)[2][4], u32x4 (&l)[2][4], int ks) {      // k-step ks: 4 reads
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint16_t* src = w + (size_t)((wave * 2 + j) * 4 + ks) * 512 + lane * 8;       // fragment order: 1 KiB per (row tile, k-step)
+            h[j][ks] = *reinterpret_cast<const u32x4*>(src);
+            l[j][ks] = *reinterpret_cast<const u32x4*>(src + p.plW);
+        }
+    };
+    const int c8 = tid & 31, rsub = tid >> 5;      // epilogue thread = (8-channel chunk c8, rows rsub + 8 u)
+    u32x4 rh[8], rl[8];
+    auto load_res = [&](int u) {                   // identity chunk of row rsub + 8 u: 2 reads
+        const int m = min(p0 + u * 8 + rsub, p.P - 1);      // rows past P repeat the last one (never stored): no branch around the read
+        rh[u] = *reinterpret_cast<const u32x4*>(p.res + (size_t)m * N1 + c8 * 8);
+        rl[u] = *reinterpret_cast<const u32x4*>(p.res + p.plRes + (size_t)m * N1 + c8 * 8);
+    };
+    constexpr int NEXTRA = 8;
+    auto extra_reads = [&](int k) {                // group k of NEXTRA, 4 reads each
+        if (k < 4) load_wfrag(p.w3, w3h, w3l, k);
+        else if constexpr (DS) load_wfrag(p.wd, wdh, wdl, k - 4);
+        else if (!(p.dbg & 2)) { load_res(2 * (k - 4)); load_res(2 * (k - 4) + 1); }
+    };
+    // A tile of a 64-deep product ([64 px][64 k] planes of t2 or of the block's input) by LDS-DMA: K-tile kt at
+    // smem + kt * KT_BYTES + a_off, hi plane then lo plane, 64-byte rows, chunk ^= (row >> 2) & 3
+    auto load_a = [&](__amdgpu_buffer_rsrc_t ah_, __amdgpu_buffer_rsrc_t al_, int a_off) {
         const int r0 = tid >> 2, gc = (tid & 3) ^ ((r0 >> 2) & 3);
         const int m = p0 + r0;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            char* buf = smem + kt * KT_BYTES + wave * 1024;
+            char* buf = smem + kt * KT_BYTES + a_off + wave * 1024;
             const uint32_t oa = m < p.P ? ((uint32_t)m * K1 + (uint32_t)(kt * 32 + gc * 8)) * 2u : OOB;
-            if (with_a) {
-                glds16(ah_, buf, oa);
-                glds16(al_, buf + A_PLANE, oa);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t ob = ((uint32_t)(j * 64 + r0) * K1 + (uint32_t)(kt * 32 + gc * 8)) * 2u;
-                glds16(bh_, buf + 2 * A_PLANE + j * 4096, ob);
-                glds16(bl_, buf + 2 * A_PLANE + B_PLANE + j * 4096, ob);
-            }
+            glds16(ah_, buf, oa);
+            glds16(al_, buf + A_PLANE, oa);
         }
     };
+    constexpr int X_OFF = 2 * A_PLANE;           // the downsample product's A tile sits behind the first product's
     if constexpr (TAIL) {
         // ---- 0. t2 = relu(conv3x3(t1) * s2 + b2) for this tile, never leaving the CU.  The tile's 64 flat pixels need the
         // contiguous rows [p0 - W - 1, p0 + 64 + W + 1) of t1 (<= 192 rows, W <= 62): both 32-channel blocks and both planes
-        // arrive at once (48 KiB); the weights stream as 18 tiles [64 n][32 k] x 2 planes through a three-stage ring.
+        // arrive at once (48 KiB); the weights stream as 18 tiles [64 n][32 k] x 2 planes through a four-stage ring (32 KiB).
         // 4 waves = 2 (32 pixels) x 2 (32 channels), 6 MFMAs per wave and step -- the same K order (channel block, tap) and
         // MFMA sequence as conv_halo_x3.hip.  The result goes to LDS as the A image of the first product.
         constexpr int HROWS = 192, HPL = HROWS * 64, HCB = 2 * HPL, WST = 8192;
@@ -157,14 +196,15 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         }
         const int wn_ = tid >> 2, wc_ = (tid & 3) ^ ((wn_ >> 2) & 3);
         auto issue_w2 = [&](int g, int stage) {
-            const int cb = g / 9, tap = g - cb * 9;
-            const uint32_t off = ((uint32_t)wn_ * 576u + (uint32_t)(tap * 64 + cb * 32 + wc_ * 8)) * 2u;
+            const uint32_t off = ((uint32_t)g * 2048u + (uint32_t)(wn_ * 32 + wc_ * 8)) * 2u;      // tile g = [64 n][32 k], contiguous
             char* dst = WR + stage * WST + wave * 1024;
             glds16(rs2h, dst, off);
             glds16(rs2l, dst + 4096, off);
         };
         issue_w2(0, 0);
         issue_w2(1, 1);
+        issue_w2(2, 2);
+        asm volatile("" ::: "memory");
         const int pi3 = wave >> 1, cj3 = wave & 1;
         const int ml = pi3 * 32 + l31;
         uint32_t mask = 0;
@@ -184,19 +224,28 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         f32x16 acc3;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
+        if (!(p.dbg & 4))
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int g = cb * 9 + tap;
-                if (g + 1 < 18) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // tile g (and the input rows) landed; tile g+1 in flight
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // tile g (and everything older) landed.  Requested after it, in this order: extra group g-3 (4 reads),
+                // tile g+1 (2), extra g-2, tile g+2, extra g-1 -- those that exist may stay in flight
+                {
+                    int n = 0;
+#pragma unroll
+                    for (int k = g - 3; k < g; ++k) n += (k >= 0 && k < NEXTRA) ? 4 : 0;
+#pragma unroll
+                    for (int j = g + 1; j <= g + 2; ++j) n += j < 18 ? 2 : 0;
+                    wait_vm_n(n);
+                }
                 __builtin_amdgcn_s_barrier();
                 const int j = jc + (tap / 3 - 1) * W + (tap % 3 - 1);
                 const char* arow = HB + cb * HCB + j * 64;
                 const int asw = (j >> 2) & 3;
                 const bool aok = (mask >> tap) & 1u;
-                const char* wt = WR + (g % 3) * WST + brow * 64;
+                const char* wt = WR + (g & 3) * WST + brow * 64;
                 const int bsw = (brow >> 2) & 3;
                 u32x4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -205,7 +254,10 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                     if (!aok) { ah[s2] = u32x4{0, 0, 0, 0}; al[s2] = u32x4{0, 0, 0, 0}; }
                     bh[s2] = lds128(wt + (((2 * s2 + lh) ^ bsw) << 4)); bl[s2] = lds128(wt + 4096 + (((2 * s2 + lh) ^ bsw) << 4));
                 }
-                if (g + 2 < 18) issue_w2(g + 2, (g + 2) % 3);          // behind the fragment reads: their latency covers the DMA issue
+                if (g + 3 < 18) issue_w2(g + 3, (g + 3) & 3);           // into the stage read at step g - 1; behind the fragment reads, whose latency covers the DMA issue
+                asm volatile("" ::: "memory");           // (the counted waits above rely on this order)
+                if (g < NEXTRA) extra_reads(g);
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     Fmt::mma(al[s2], bh[s2], acc3);
@@ -214,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                 }
             }
         __syncthreads();                         // the input rows and the weight ring are dead
-        load_operands(rsTh, rsTl, rsWh, rsWl, false);          // w3 only: t2 comes from the registers
+        if constexpr (DS) load_a(rsXh, rsXl, X_OFF);           // the block's input tile for the downsample product
         {
             const float s2v = p.cs2 ? p.cs2[brow] : 1.f, b2v = p.b2[brow];
             const int ck = (brow & 31) >> 3;       // K-tile of the image = channel / 32 (= cj3), 16-byte chunk ck, byte (channel & 7) * 2
@@ -233,10 +285,12 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             }
         }
     } else {
-        load_operands(rsTh, rsTl, rsWh, rsWl, true);
+        load_a(rsTh, rsTl, 0);
+        if constexpr (DS) load_a(rsXh, rsXl, X_OFF);
+#pragma unroll
+        for (int k = 0; k < NEXTRA; ++k) extra_reads(k);
     }
     // epilogue constants of this thread's 8-channel chunk
-    const int c8 = tid & 31, rsub = tid >> 5;
     float bias8[8], scale8[8];
     {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b3 + c8 * 8), b1 = *reinterpret_cast<const f32x4*>(p.b3 + c8 * 8 + 4);
@@ -249,8 +303,8 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         }
     }
 
-    // ---- a 64-deep product from the staged operands: 64 px x channels [64 wave, +64), 48 MFMAs per wave
-    auto product = [&](f32x16 (&acc_)[2][2]) {
+    // ---- a 64-deep product: 64 px (A tile in LDS at a_off) x channels [64 wave, +64) (B in registers), 48 MFMAs per wave
+    auto product = [&](f32x16 (&acc_)[2][2], const u32x4 (&bh)[2][4], const u32x4 (&bl)[2][4], int a_off) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -258,51 +312,39 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc_[i][j][e] = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const char* st = smem + kt * KT_BYTES;
+        for (int ks = 0; ks < 4; ++ks) {
+            const char* st = smem + (ks >> 1) * KT_BYTES + a_off;
+            const int s = ks & 1;
+            u32x4 ah[2], al[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                u32x4 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = i * 32 + l31;
-                    const int off = row * 64 + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4);
-                    ah[i] = lds128(st + off); al[i] = lds128(st + A_PLANE + off);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int row = wave * 64 + j * 32 + l31;
-                    const int off = 2 * A_PLANE + row * 64 + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4);
-                    bh[j] = lds128(st + off); bl[j] = lds128(st + B_PLANE + off);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) Fmt::mma(al[i], bh[j], acc_[i][j]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) Fmt::mma(ah[i], bl[j], acc_[i][j]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) Fmt::mma(ah[i], bh[j], acc_[i][j]);
+            for (int i = 0; i < 2; ++i) {
+                const int row = i * 32 + l31;
+                const int off = row * 64 + (((2 * s + lh) ^ ((row >> 2) & 3)) << 4);
+                ah[i] = lds128(st + off); al[i] = lds128(st + A_PLANE + off);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Fmt::mma(al[i], bh[j][ks], acc_[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Fmt::mma(ah[i], bl[j][ks], acc_[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Fmt::mma(ah[i], bh[j][ks], acc_[i][j]);
         }
     };
     f32x16 acc[2][2];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    product(acc);
+    product(acc, w3h, w3l, 0);
     if constexpr (DS) {
-        // the downsample product through the same buffers; its result joins the first one in registers exactly as the two
-        // launches would: identity = join(split(acc_d * s_d + b_d)) (the stored planes' rounding), y = relu((acc * s3 + b3) + identity)
+        // the downsample product; its result joins the first one in registers exactly as the two launches would:
+        // identity = join(split(acc_d * s_d + b_d)) (the stored planes' rounding), y = relu((acc * s3 + b3) + identity)
         f32x16 accd[2][2];
-        __syncthreads();                         // every wave has read the first product's fragments
-        load_operands(rsXh, rsXl, rsDh, rsDl, true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        product(accd);
+        product(accd, wdh, wdl, X_OFF);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = wave * 64 + j * 32 + l31;
@@ -332,26 +374,14 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                 const int col = wave * 64 + j * 32 + l31;
                 *reinterpret_cast<float*>(smem + row * YROW + ((((col >> 3) ^ (row & 31))) << 5) + (col & 7) * 4) = acc[i][j][r];
             }
-    load_w1(0, 0);
+#pragma unroll
+    for (int g = 0; g < W1PRE; ++g) load_w1(g, g);
     __syncthreads();
-    // epilogue of the first product: thread = (chunk c8, rows rsub + 8 u)
+    // epilogue of the first product: thread = (chunk c8, rows rsub + 8 u); the identity has been in registers since the top
     {
-        const uint16_t* resh = p.res;
 #pragma unroll
-        for (int u0 = 0; u0 < 8; u0 += 4) {
-        u32x4 rh[4], rl[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int m = p0 + (u0 + u) * 8 + rsub;
-            rh[u] = u32x4{0, 0, 0, 0}; rl[u] = u32x4{0, 0, 0, 0};
-            if (!DS && m < p.P) {
-                rh[u] = *reinterpret_cast<const u32x4*>(resh + (size_t)m * N1 + c8 * 8);
-                rl[u] = *reinterpret_cast<const u32x4*>(resh + p.plRes + (size_t)m * N1 + c8 * 8);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = (u0 + u) * 8 + rsub;
+        for (int u = 0; u < 8; ++u) {
+            const int row = u * 8 + rsub;
             const int m = p0 + row;
             char* chunk = smem + row * YROW + ((c8 ^ (row & 31)) << 5);
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(chunk), a1 = *reinterpret_cast<const f32x4*>(chunk + 16);
@@ -364,13 +394,12 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             }
             u32x4 hi, lo;
             x3_split8<F16>(v, hi, lo);
-            *reinterpret_cast<u32x4*>(chunk) = hi;                  // rows past P hold relu(bias): never stored, and their t1' rows neither
+            *reinterpret_cast<u32x4*>(chunk) = hi;                  // rows past P: never stored, and their t1' rows neither
             *reinterpret_cast<u32x4*>(chunk + 16) = lo;
-            if (m < p.P) {
+            if (m < p.P && !(p.dbg & 1)) {
                 *reinterpret_cast<u32x4*>(p.y + (size_t)m * N1 + c8 * 8) = hi;
                 *reinterpret_cast<u32x4*>(p.y + p.plY + (size_t)m * N1 + c8 * 8) = lo;
             }
-        }
         }
     }
     __syncthreads();                             // y image complete
@@ -381,9 +410,12 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     for (int i = 0; i < NI2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+    if (!(p.dbg & 8))
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if (g < 3) load_w1(g + 1, (g + 1) & 1);
+        if (g == 0)
+#pragma unroll
+            for (int g2 = W1PRE; g2 < 4; ++g2) load_w1(g2, g2);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int s = g * 4 + s4;
@@ -395,11 +427,11 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                 ah[i] = lds128(cp); al[i] = lds128(cp + 16);
             }
 #pragma unroll
-            for (int i = 0; i < NI2; ++i) Fmt::mma(al[i], wbh[g & 1][s4], acc2[i]);
+            for (int i = 0; i < NI2; ++i) Fmt::mma(al[i], wbh[g][s4], acc2[i]);
 #pragma unroll
-            for (int i = 0; i < NI2; ++i) Fmt::mma(ah[i], wbl[g & 1][s4], acc2[i]);
+            for (int i = 0; i < NI2; ++i) Fmt::mma(ah[i], wbl[g][s4], acc2[i]);
 #pragma unroll
-            for (int i = 0; i < NI2; ++i) Fmt::mma(ah[i], wbh[g & 1][s4], acc2[i]);
+            for (int i = 0; i < NI2; ++i) Fmt::mma(ah[i], wbh[g][s4], acc2[i]);
         }
     }
     __syncthreads();                             // the y image is dead: its head becomes the t1' stage
@@ -430,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         for (int u = 0; u < PASSES; ++u) {
             const int row = u * RPP + e_r;
             const int m = p0 + row;
-            if (m >= p.P) continue;
+            if (m >= p.P || (p.dbg & 1)) continue;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * N2 + e_c8 * 8);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * N2 + e_c8 * 8 + 4);
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -444,7 +476,41 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     }
 }
 
+// ---- fragment-ordered weight copies.  The launch above streams ~275 KiB of weights per 64-pixel tile through the CU's
+// vector-memory path, which is as busy as HBM here: read row-major, a B-fragment request touches 32
+// cache lines for 1 KiB (w3 / wd / w1': 16 bytes per lane from 32 rows) and a ring tile request 16 (w2: 64 bytes from 16
+// rows).  This kernel lays the block's weights out in the order the requests want them -- every wave-wide request one
+// contiguous 1 KiB -- in front of each launch (a few microseconds; the weights' ABI layout stays row-major):
+//   plane of SQ_CHAIN_X3_FRAG elements:  w3 @0        [(wave, j)][ks][lane][8]   row = 32 (2 wave + j) + lane % 32, k = 16 ks + 8 (lane / 32)
+//                                        w1' @16384   [cj][ks 0..15][lane][8]    row = 32 cj + lane % 32,          k = 16 ks + 8 (lane / 32)
+//                                        wd @49152    as w3
+//                                        w2 @65536    [g = cb * 9 + tap][n][32]  k = tap * 64 + cb * 32 + ..
+constexpr int FRAG = 102400, FRAG_W1 = 16384, FRAG_WD = 49152, FRAG_W2 = 65536;
+__global__ __launch_bounds__(256) void chain_x3_pack_kernel(const uint16_t* w3, const uint16_t* w1n, const uint16_t* wd, const uint16_t* w2,
+                                                            long long plSrc, int n2, uint16_t* dst) {
+    const int c = blockIdx.x * 256 + threadIdx.x;            // one 16-byte chunk of one plane
+    if (c >= 2 * (FRAG / 8)) return;
+    const int pl = c >= FRAG / 8, e0 = (c - pl * (FRAG / 8)) * 8;
+    const uint16_t* src = nullptr;
+    if (e0 < FRAG_W1 || (e0 >= FRAG_WD && e0 < FRAG_W2)) {
+        const bool d = e0 >= FRAG_WD;
+        const int r = e0 - (d ? FRAG_WD : 0), q = r >> 9, lane = (r & 511) >> 3;
+        const uint16_t* w = d ? wd : w3;
+        if (w) src = w + ((q >> 2) * 32 + (lane & 31)) * K1 + (q & 3) * 16 + (lane >> 5) * 8;
+    } else if (e0 < FRAG_WD) {
+        const int r = e0 - FRAG_W1, q = r >> 9, lane = (r & 511) >> 3;
+        if ((q >> 4) * 32 < n2) src = w1n + ((q >> 4) * 32 + (lane & 31)) * N1 + (q & 15) * 16 + (lane >> 5) * 8;
+    } else if (w2) {
+        const int r = e0 - FRAG_W2, g = r >> 11, n = (r & 2047) >> 5, kk = r & 31;
+        const int cb = g / 9, tap = g - cb * 9;
+        src = w2 + n * 576 + tap * 64 + cb * 32 + kk;
+    }
+    if (src) *reinterpret_cast<u32x4*>(dst + (size_t)pl * FRAG + e0) = *reinterpret_cast<const u32x4*>(src + (size_t)pl * plSrc);
+}
+
 }  // namespace
+
+size_t sq_chain_x3_frag_bytes() { return (size_t)2 * FRAG * 2; }
 
 // t2 [P, 64], res / y [P, 256], t1n [P, n2] (n2 = 64 or 128) as hi / lo planes (pl* = elements between the planes);
 // w3 [256, 64] and w1n [n2, 256] planes plW apart, biases / per-channel scales fp32 (scales may be null).
@@ -456,23 +522,27 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
                            const float* b3, const float* cs3, const float* b1n, const float* cs1n,
                            const uint16_t* xin, long long plX, const uint16_t* wd, size_t wd_bytes, const float* bd, const float* csd,
                            const uint16_t* t1, long long plT1, const uint16_t* w2, size_t w2_bytes, const float* b2, const float* cs2, int W, int HW,
-                           long long P, hipStream_t stream) {
+                           long long P, uint16_t* frag, hipStream_t stream) {
     SQ_REQUIRE(n2 == 64 || n2 == 128, "chain_x3: next width %d (64 or 128)", n2);
     SQ_REQUIRE(P > 0 && P * N1 * 2 < (1ll << 31), "chain_x3: %lld pixels exceed the 2 GiB descriptor limit", P);
     const bool tail = t1 != nullptr;
-    SQ_REQUIRE((t2 || tail) && y && t1n && w3 && w1n && b3 && b1n && w3_bytes >= (size_t)N1 * K1 * 2, "chain_x3: null pointer / weight extent");
+    SQ_REQUIRE((t2 || tail) && y && t1n && w3 && w1n && b3 && b1n && frag && w3_bytes >= (size_t)N1 * K1 * 2, "chain_x3: null pointer / weight extent");
     SQ_REQUIRE(!tail || (w2 && b2 && w2_bytes >= (size_t)64 * 576 * 2 && W >= 3 && W <= 62 && HW == W * W && P % HW == 0),
                "chain_x3: tail form needs the 3x3 weights and square maps up to 62 wide (W=%d)", W);
     const bool ds = res == nullptr;
     SQ_REQUIRE(!ds || (xin && wd && bd && wd_bytes >= (size_t)N1 * K1 * 2), "chain_x3: neither an identity tensor nor a downsample branch");
     ChainX3Args a;
-    a.t2 = t2; a.plT2 = plT2; a.w3 = w3; a.w1n = w1n; a.plW = plW; a.b3 = b3; a.cs3 = cs3; a.b1n = b1n; a.cs1n = cs1n;
+    // the kernel reads the fragment-ordered copies (frag: sq_chain_x3_frag_bytes() of scratch, rewritten by every launch)
+    hipLaunchKernelGGL(chain_x3_pack_kernel, dim3((2 * (FRAG / 8) + 255) / 256), dim3(256), 0, stream, w3, w1n, ds ? wd : nullptr,
+                       tail ? w2 : nullptr, plW, n2, frag);
+    SQ_LAUNCH_CHECK();
+    a.t2 = t2; a.plT2 = plT2; a.w3 = frag; a.w1n = frag + FRAG_W1; a.plW = FRAG; a.b3 = b3; a.cs3 = cs3; a.b1n = b1n; a.cs1n = cs1n;
     a.res = res; a.plRes = plRes; a.y = y; a.plY = plY; a.t1n = t1n; a.plT1n = plT1n; a.P = (int)P;
     a.t2_bytes = (uint32_t)(P * K1 * 2);
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
     a.w3_bytes = clamp(w3_bytes);
-    a.xin = xin; a.plX = plX; a.wd = wd; a.bd = bd; a.csd = csd; a.wd_bytes = clamp(wd_bytes);
-    a.t1 = t1; a.plT1 = plT1; a.w2 = w2; a.b2 = b2; a.cs2 = cs2; a.w2_bytes = clamp(w2_bytes); a.W = W; a.HW = HW;
+    a.xin = xin; a.plX = plX; a.wd = frag + FRAG_WD; a.bd = bd; a.csd = csd; a.wd_bytes = clamp(wd_bytes);
+    a.t1 = t1; a.plT1 = plT1; a.w2 = frag + FRAG_W2; a.b2 = b2; a.cs2 = cs2; a.w2_bytes = (uint32_t)((FRAG - FRAG_W2) * 2); a.W = W; a.HW = HW; a.dbg = g_dbg;
     using I64 = std::integral_constant<int, 64>; using I128 = std::integral_constant<int, 128>;
     using T = std::true_type; using F = std::false_type;
     auto pick_tail = [&](auto n2c, auto f16c, auto dsc) {
@@ -494,4 +564,21 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     SQ_HIP_CHECK(hipLaunchKernel(fn, grid, block, kargs, LDS_BYTES, stream));
     if (prof >= 0) sq_prof_end(prof, stream);
     return SQ_OK;
+}
+
+// Probe entry (tools/chain_probe.py): one launch over caller-provided scratch, laid out as
+//   act (uint16): t1 [2][P*64] | res [2][P*256] | y [2][P*256] | t1n [2][P*128]      (hi plane, lo plane)
+//   wts (uint16): two planes of 102400 elements, row-major: w3 @0, w1n @16384, wd @49152, w2 @65536;  frag: as much again
+//   fp  (float):  b3 @0, cs3 @256, b1n @512, cs1n @640, bd @768, csd @1024, b2 @1280, cs2 @1344
+extern "C" int sq_dbg_chain_x3(int f16, int n2, int ds, int tail, long long P, int W, void* act, void* wts, void* fp, void* frag, void* stream) {
+    uint16_t* a = (uint16_t*)act;
+    const uint16_t* w = (const uint16_t*)wts;
+    const float* f = (const float*)fp;
+    uint16_t* t1 = a; uint16_t* res = t1 + 2 * P * 64; uint16_t* y = res + 2 * P * 256; uint16_t* t1n = y + 2 * P * 256;
+    const long long plW = 102400;
+    return sq_launch_chain_x3_c64(f16, tail ? nullptr : t1, P * 64, ds ? nullptr : res, P * 256, y, P * 256, t1n, P * 128, n2,
+                                  w, w + 16384, plW, (size_t)(plW * 2), f, f + 256, f + 512, f + 640,
+                                  ds ? t1 : nullptr, P * 64, ds ? w + 49152 : nullptr, (size_t)(plW - 49152) * 2, ds ? f + 768 : nullptr, ds ? f + 1024 : nullptr,
+                                  tail ? t1 : nullptr, P * 64, tail ? w + 65536 : nullptr, (size_t)(plW - 65536) * 2, tail ? f + 1280 : nullptr,
+                                  tail ? f + 1344 : nullptr, W, W * W, P, (uint16_t*)frag, (hipStream_t)stream);
 }

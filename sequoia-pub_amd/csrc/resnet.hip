@@ -34,7 +34,8 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
                            const float* b3, const float* cs3, const float* b1n, const float* cs1n,
                            const uint16_t* xin, long long plX, const uint16_t* wd, size_t wd_bytes, const float* bd, const float* csd,
                            const uint16_t* t1, long long plT1, const uint16_t* w2, size_t w2_bytes, const float* b2, const float* cs2, int W, int HW,
-                           long long P, hipStream_t stream);
+                           long long P, uint16_t* frag, hipStream_t stream);
+size_t sq_chain_x3_frag_bytes();
 int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, const uint16_t* w152_hi, long long w_plane, const float* bias,
                             const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream);
 
@@ -196,7 +197,7 @@ void build_specs(ConvSpec* specs) {
         }
 }
 
-struct RnBufs { void* col; void* act[5]; size_t bytes; };
+struct RnBufs { void* col; void* act[5]; void* frag; size_t bytes; };
 
 void rn_bufs(int dtype, int n, int S, char* base, RnBufs* o) {
     size_t off = 0;
@@ -206,6 +207,7 @@ void rn_bufs(int dtype, int n, int S, char* base, RnBufs* o) {
     o->col = dtype == SQ_F32 ? take((size_t)n * OH * OH * CONV1_KP * es) : nullptr;    // bf16 and the split modes: fused stem, no im2col matrix
     const size_t act = (size_t)n * OH * OH * 64 * es;          // largest activation: conv1 out == layer1 out
     for (int i = 0; i < 5; ++i) o->act[i] = take(act);
+    o->frag = (dtype == SQ_BF16X3 || dtype == SQ_F16X3) ? take(sq_chain_x3_frag_bytes()) : nullptr;     // chain_x3.hip's fragment-ordered weights
     o->bytes = sq_align_up(off, 256);
 }
 
@@ -382,7 +384,7 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                                            has_ds ? rest(dsd) : 0, has_ds ? bias + dsd.b_off : nullptr, has_ds ? colscale + dsd.b_off : nullptr,
                                            x3_tail ? (const uint16_t*)t1 : nullptr, act_plane, x3_tail ? (const uint16_t*)W(c2) : nullptr,
                                            x3_tail ? rest(c2) : 0, x3_tail ? bias + c2.b_off : nullptr, x3_tail ? colscale + c2.b_off : nullptr, H, H * H,
-                                           (long long)n * OH * OH, st));
+                                           (long long)n * OH * OH, (uint16_t*)b.frag, st));
                 ci = cnext;
                 xi = free_[2];
                 t1i = x3_tail ? free_[0] : t1_idx;
