@@ -610,7 +610,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=2, help="train_kfold workload: epochs per fold")
     ap.add_argument("--slides", type=int, default=8, help="pipeline workload: slides per GPU per step")
     ap.add_argument("--patches", type=int, default=1000, help="pipeline workload: patches per slide")
-    ap.add_argument("--sub-batch", type=int, default=500, help="pipeline workload: patches per ResNet launch group")
+    ap.add_argument("--sub-batch", type=int, default=1000, help="pipeline workload: patches per ResNet launch group (two groups in flight)")
     ap.add_argument("--grid", type=int, nargs=2, default=[250, 200], help="spatial workload: tile grid")
     ap.add_argument("--batch-windows", type=int, default=1024, help="spatial workload: windows per ViS forward")
     ap.add_argument("--embedder", default="resnet", choices=["resnet", "uni"], help="pipeline workload: patch embedder")

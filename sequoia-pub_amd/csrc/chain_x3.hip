@@ -486,8 +486,11 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
 //                                        wd @49152    as w3
 //                                        w2 @65536    [g = cb * 9 + tap][n][32]  k = tap * 64 + cb * 32 + ..
 constexpr int FRAG = 102400, FRAG_W1 = 16384, FRAG_WD = 49152, FRAG_W2 = 65536;
+// Source weights: row-major [n][K], or K-tile-major (tiled: element (n, k) at ((k / 32) * N + n) * 32 + k % 32, the layout the
+// split modes' GEMM launches read, gemm.h b_tiled).
 __global__ __launch_bounds__(256) void chain_x3_pack_kernel(const uint16_t* w3, const uint16_t* w1n, const uint16_t* wd, const uint16_t* w2,
-                                                            long long plSrc, int n2, uint16_t* dst) {
+                                                            long long plSrc, int n2, int tiled, uint16_t* dst) {
+    auto at = [&](const uint16_t* w, int n, int k, int N, int K) { return tiled ? w + ((size_t)(k >> 5) * N + n) * 32 + (k & 31) : w + (size_t)n * K + k; };
     const int c = blockIdx.x * 256 + threadIdx.x;            // one 16-byte chunk of one plane
     if (c >= 2 * (FRAG / 8)) return;
     const int pl = c >= FRAG / 8, e0 = (c - pl * (FRAG / 8)) * 8;
@@ -496,14 +499,14 @@ __global__ __launch_bounds__(256) void chain_x3_pack_kernel(const uint16_t* w3, 
         const bool d = e0 >= FRAG_WD;
         const int r = e0 - (d ? FRAG_WD : 0), q = r >> 9, lane = (r & 511) >> 3;
         const uint16_t* w = d ? wd : w3;
-        if (w) src = w + ((q >> 2) * 32 + (lane & 31)) * K1 + (q & 3) * 16 + (lane >> 5) * 8;
+        if (w) src = at(w, (q >> 2) * 32 + (lane & 31), (q & 3) * 16 + (lane >> 5) * 8, N1, K1);
     } else if (e0 < FRAG_WD) {
         const int r = e0 - FRAG_W1, q = r >> 9, lane = (r & 511) >> 3;
-        if ((q >> 4) * 32 < n2) src = w1n + ((q >> 4) * 32 + (lane & 31)) * N1 + (q & 15) * 16 + (lane >> 5) * 8;
+        if ((q >> 4) * 32 < n2) src = at(w1n, (q >> 4) * 32 + (lane & 31), (q & 15) * 16 + (lane >> 5) * 8, n2, N1);
     } else if (w2) {
         const int r = e0 - FRAG_W2, g = r >> 11, n = (r & 2047) >> 5, kk = r & 31;
         const int cb = g / 9, tap = g - cb * 9;
-        src = w2 + n * 576 + tap * 64 + cb * 32 + kk;
+        src = at(w2, n, tap * 64 + cb * 32 + kk, 64, 576);
     }
     if (src) *reinterpret_cast<u32x4*>(dst + (size_t)pl * FRAG + e0) = *reinterpret_cast<const u32x4*>(src + (size_t)pl * plSrc);
 }
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(256) void chain_x3_pack_kernel(const uint16_t* w3, 
 size_t sq_chain_x3_frag_bytes() { return (size_t)2 * FRAG * 2; }
 
 // t2 [P, 64], res / y [P, 256], t1n [P, n2] (n2 = 64 or 128) as hi / lo planes (pl* = elements between the planes);
-// w3 [256, 64] and w1n [n2, 256] planes plW apart, biases / per-channel scales fp32 (scales may be null).
+// w3 [256, 64] and w1n [n2, 256] planes plW apart (row-major, or K-tile-major when w_tiled), biases / per-channel scales fp32 (scales may be null).
 // Downsample form: res == nullptr, the identity is xin [P, 64] . wd^T * csd + bd (wd [256, 64], planes plW apart).
 // Tail form: t1 != nullptr -- t2 is not read but computed in the launch as relu(conv3x3(t1) * cs2 + b2) (w2 [64, 576]).
 // w3_bytes / wd_bytes: bytes from the pointer to the end of one weight plane's allocation (descriptor extent).
@@ -522,7 +525,7 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
                            const float* b3, const float* cs3, const float* b1n, const float* cs1n,
                            const uint16_t* xin, long long plX, const uint16_t* wd, size_t wd_bytes, const float* bd, const float* csd,
                            const uint16_t* t1, long long plT1, const uint16_t* w2, size_t w2_bytes, const float* b2, const float* cs2, int W, int HW,
-                           long long P, uint16_t* frag, hipStream_t stream) {
+                           long long P, uint16_t* frag, int w_tiled, hipStream_t stream) {
     SQ_REQUIRE(n2 == 64 || n2 == 128, "chain_x3: next width %d (64 or 128)", n2);
     SQ_REQUIRE(P > 0 && P * N1 * 2 < (1ll << 31), "chain_x3: %lld pixels exceed the 2 GiB descriptor limit", P);
     const bool tail = t1 != nullptr;
@@ -534,7 +537,7 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     ChainX3Args a;
     // the kernel reads the fragment-ordered copies (frag: sq_chain_x3_frag_bytes() of scratch, rewritten by every launch)
     hipLaunchKernelGGL(chain_x3_pack_kernel, dim3((2 * (FRAG / 8) + 255) / 256), dim3(256), 0, stream, w3, w1n, ds ? wd : nullptr,
-                       tail ? w2 : nullptr, plW, n2, frag);
+                       tail ? w2 : nullptr, plW, n2, w_tiled, frag);
     SQ_LAUNCH_CHECK();
     a.t2 = t2; a.plT2 = plT2; a.w3 = frag; a.w1n = frag + FRAG_W1; a.plW = FRAG; a.b3 = b3; a.cs3 = cs3; a.b1n = b1n; a.cs1n = cs1n;
     a.res = res; a.plRes = plRes; a.y = y; a.plY = plY; a.t1n = t1n; a.plT1n = plT1n; a.P = (int)P;
@@ -580,5 +583,5 @@ extern "C" int sq_dbg_chain_x3(int f16, int n2, int ds, int tail, long long P, i
                                   w, w + 16384, plW, (size_t)(plW * 2), f, f + 256, f + 512, f + 640,
                                   ds ? t1 : nullptr, P * 64, ds ? w + 49152 : nullptr, (size_t)(plW - 49152) * 2, ds ? f + 768 : nullptr, ds ? f + 1024 : nullptr,
                                   tail ? t1 : nullptr, P * 64, tail ? w + 65536 : nullptr, (size_t)(plW - 65536) * 2, tail ? f + 1280 : nullptr,
-                                  tail ? f + 1344 : nullptr, W, W * W, P, (uint16_t*)frag, (hipStream_t)stream);
+                                  tail ? f + 1344 : nullptr, W, W * W, P, (uint16_t*)frag, 0, (hipStream_t)stream);
 }

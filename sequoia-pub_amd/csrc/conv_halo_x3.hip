@@ -106,9 +106,10 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
     // weight tile [n0 + n][tap*C + cb*32 + 0..31], hi plane then lo plane.  BN = 128: one instruction per plane;
     // BN = 64: one instruction for both (waves 0-3 the hi plane, waves 4-7 the lo plane)
     const int br0 = (tid >> 2) & (BN - 1), bc = (tid & 3) ^ ((br0 >> 2) & 3);
-    const uint32_t b_row = (uint32_t)(n0 + br0) * (uint32_t)p.ldb + (uint32_t)(bc * 8);
+    const uint32_t b_row = p.b_tiled ? (uint32_t)(n0 + br0) * 32u + (uint32_t)(bc * 8) : (uint32_t)(n0 + br0) * (uint32_t)p.ldb + (uint32_t)(bc * 8);
     auto issue_wtile = [&](int cb, int tap, int stage) {
-        const uint32_t off = (b_row + (uint32_t)(tap * C + cb * CB)) * 2u;
+        const int k0 = tap * C + cb * CB;
+        const uint32_t off = (b_row + (p.b_tiled ? (uint32_t)(k0 >> 5) * (uint32_t)p.N * 32u : (uint32_t)k0)) * 2u;
         char* dst = WR + stage * BT_BYTES + wave * 1024;
         if constexpr (WTN == 2) {
             glds16(rsBh, dst, off);

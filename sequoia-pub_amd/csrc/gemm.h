@@ -52,6 +52,8 @@ struct GemmArgs {
     void* gC[4] = {nullptr, nullptr, nullptr, nullptr};
     float* gcs[4] = {nullptr, nullptr, nullptr, nullptr};
     int vec_epi = 0;                   // set by sq_launch_gemm: all epilogue operands allow 16-byte accesses
+    int b_tiled = 0;                   // split modes: B is K-tile-major -- element (n, k) at ((k / 32) * N + n) * 32 + k % 32 of its plane (K % 32 == 0):
+                                       // a K-tile of BN rows is one contiguous run, every LDS-DMA request whole cache lines
     int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };
 

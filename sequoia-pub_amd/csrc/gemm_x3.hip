@@ -123,7 +123,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
 #pragma unroll
     for (int j = 0; j < RBP; ++j) {
         const int n = n0 + (Cfg::SPLIT_B ? (r0 & 63) : r0 + ROUND * j);
-        b_off[j] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(gc * 8)) * 2u : OOB;
+        b_off[j] = n >= p.N ? OOB : p.b_tiled ? ((uint32_t)n * 32u + (uint32_t)(gc * 8)) * 2u : ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(gc * 8)) * 2u;
     }
     auto issue_loads = [&](int kt, int buf) {
         const int k0 = kt * BK;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             }
 #pragma unroll
             for (int j = 0; j < RBP; ++j) {
-                const uint32_t ob = k_ok ? b_off[j] + (uint32_t)(k0 * 2) : OOB;
+                const uint32_t ob = k_ok ? b_off[j] + (p.b_tiled ? (uint32_t)kt * (uint32_t)p.N * 64u : (uint32_t)(k0 * 2)) : OOB;
                 if constexpr (Cfg::SPLIT_B) {
                     if (b_lo_half) glds16(rsBl, sb, ob, 0); else glds16(rsBh, sb, ob, 0);
                 } else {
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             }
         } else {
             const int soff = (p.dbg & 16) ? k0 * 4 : k0 * 2;     // dbg 16 (x3_probe.py): hi / lo interleaved per 32-element block
+            const int soffb = p.b_tiled ? kt * p.N * 64 : soff;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t off = k_ok ? a_off[j] : OOB;
@@ -164,10 +165,10 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             for (int j = 0; j < RBP; ++j) {
                 const uint32_t ob = k_ok ? b_off[j] : OOB;
                 if constexpr (Cfg::SPLIT_B) {
-                    if (b_lo_half) glds16(rsBl, sb, ob, soff); else glds16(rsBh, sb, ob, soff);
+                    if (b_lo_half) glds16(rsBl, sb, ob, soffb); else glds16(rsBh, sb, ob, soffb);
                 } else {
-                    glds16(rsBh, sb + j * (ROUND * ROWB), ob, soff);
-                    glds16(rsBl, sb + B_BYTES + j * (ROUND * ROWB), ob, soff);
+                    glds16(rsBh, sb + j * (ROUND * ROWB), ob, soffb);
+                    glds16(rsBl, sb + B_BYTES + j * (ROUND * ROWB), ob, soffb);
                 }
             }
         }
@@ -472,6 +473,7 @@ int sq_launch_gemm_x3(const GemmArgs& a_in, hipStream_t stream) {
     SQ_REQUIRE(!a.rowbias && !a.Cpre && !a.gelu_grad_of && !a.ln64_g && !a.C2 && (a.act == SQ_ACT_NONE || a.act == SQ_ACT_RELU),
                "gemm_x3: only bias / residual / ReLU epilogues");
     SQ_REQUIRE((!a.bias || ((uintptr_t)a.bias & 15) == 0) && (!a.colscale || ((uintptr_t)a.colscale & 15) == 0), "gemm_x3: bias / colscale must be 16-byte aligned");
+    SQ_REQUIRE(!a.b_tiled || a.K % BK == 0, "gemm_x3: K-tile-major weights need K %% %d == 0 (K=%d)", BK, a.K);
     if (a.conv) SQ_REQUIRE(a.Cin % BK == 0, "conv_x3: Cin=%d must be a multiple of the K-tile (%d)", a.Cin, BK);
     else SQ_REQUIRE(a.lda % 8 == 0, "gemm_x3: lda=%d must be a multiple of 8", a.lda);
     int prof = -1;

@@ -34,7 +34,7 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
                            const float* b3, const float* cs3, const float* b1n, const float* cs1n,
                            const uint16_t* xin, long long plX, const uint16_t* wd, size_t wd_bytes, const float* bd, const float* csd,
                            const uint16_t* t1, long long plT1, const uint16_t* w2, size_t w2_bytes, const float* b2, const float* cs2, int W, int HW,
-                           long long P, uint16_t* frag, hipStream_t stream);
+                           long long P, uint16_t* frag, int w_tiled, hipStream_t stream);
 size_t sq_chain_x3_frag_bytes();
 int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, const uint16_t* w152_hi, long long w_plane, const float* bias,
                             const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream);
@@ -287,6 +287,7 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
         if (x3) {
             g.plA = act_plane; g.plC = act_plane; g.plRes = act_plane; g.plB = lay.w_total;
             g.x3_f16 = f16; g.colscale = colscale + d.b_off;
+            g.b_tiled = 1;             // every convolution behind the stem: K-tile-major planes (resnet.py split_planes)
             return sq_launch_gemm_x3(g, st);
         }
         return sq_launch_gemm(g, dtype, st);
@@ -384,7 +385,7 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                                            has_ds ? rest(dsd) : 0, has_ds ? bias + dsd.b_off : nullptr, has_ds ? colscale + dsd.b_off : nullptr,
                                            x3_tail ? (const uint16_t*)t1 : nullptr, act_plane, x3_tail ? (const uint16_t*)W(c2) : nullptr,
                                            x3_tail ? rest(c2) : 0, x3_tail ? bias + c2.b_off : nullptr, x3_tail ? colscale + c2.b_off : nullptr, H, H * H,
-                                           (long long)n * OH * OH, (uint16_t*)b.frag, st));
+                                           (long long)n * OH * OH, (uint16_t*)b.frag, 1, st));
                 ci = cnext;
                 xi = free_[2];
                 t1i = x3_tail ? free_[0] : t1_idx;

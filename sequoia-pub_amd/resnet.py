@@ -83,6 +83,15 @@ def split_planes(w, b, dtype, lay=None):
         hdt = torch.float16
     else:
         hdt = torch.bfloat16
+    # every convolution behind the stem in K-tile-major order: element (n, k) at ((k // 32) * cout + n) * 32 + k % 32 of its
+    # block, so that a 32-deep K-tile of consecutive output channels is one contiguous run (the kernels' weight requests
+    # then cover whole cache lines; csrc/gemm.h b_tiled).  The stem's [64][152] rows are read straight into registers.
+    if w is not None:
+        w = w.clone()
+        for i in range(1, len(lay.conv)):
+            d = lay.conv[i]
+            blk = w[d.w_off:d.w_off + d.cout * d.k_padded]
+            blk.copy_(blk.view(d.cout, d.k_padded // 32, 32).permute(1, 0, 2).reshape(-1))
     hi = w.to(hdt)
     lo = (w - hi.float()).to(hdt)
     return torch.cat([hi, lo]).view(torch.int16), torch.cat([b, scale])

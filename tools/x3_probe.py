@@ -58,8 +58,7 @@ def probe_interleaved(M, N, K):
     C = torch.empty(2, M, N, device="cuda", dtype=torch.float16)
     bias = torch.randn(N, device="cuda")
     flops = 2.0 * M * N * K
-    lib.sq_dbg_set(7, 0)
-    for dbg in (16, 16 | 4, 16 | 2):
+    for dbg in (16,):
         lib.sq_dbg_set(1, dbg)
         fn = lambda: _lib.check(lib.sq_linear_x3(1, _lib.ptr(A), A.data_ptr() + 64, 2 * K, _lib.ptr(W), W.data_ptr() + 64, 2 * K, _lib.ptr(bias), None,
                                                  None, None, N, 2, _lib.ptr(C[0]), _lib.ptr(C[1]), None, N, M, N, K, None, _lib.stream_ptr()))
@@ -70,9 +69,20 @@ def probe_interleaved(M, N, K):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "km":
+        # K-tile-major weight addressing (dbg 32, timing only) against the row-major default
+        probe(98000, 256, 2304, conv=(500, 14, 256), res=False, shapes=(-1,), dbgs=(0, 32))
+        probe(392000, 128, 1152, conv=(500, 28, 128), res=False, shapes=(-1,), dbgs=(0, 32))
+        probe(24500, 512, 4608, conv=(500, 7, 512), res=False, shapes=(-1,), dbgs=(0, 32))
+        for M, N, K in [(392000, 512, 128), (98000, 1024, 256), (98000, 256, 1024), (392000, 128, 512), (24500, 2048, 512), (24500, 512, 2048)]:
+            probe(M, N, K, res=True, shapes=(-1,), dbgs=(0, 32))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "il":
-        for M, N, K in [(98000, 256, 2304), (98000, 256, 1024), (24500, 512, 4608)]:
-            probe(M, N, K, res=False, shapes=(0,), dbgs=(0, 4, 2))
+        shapes = [(98000, 256, 2304), (98000, 256, 1024), (24500, 512, 4608)]
+        if len(sys.argv) > 2:
+            shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]]
+        for M, N, K in shapes:
+            probe(M, N, K, res=False, shapes=(-1,), dbgs=(0,))
             probe_interleaved(M, N, K)
         sys.exit(0)
     probe(98000, 256, 2304, conv=(500, 14, 256), res=False)
