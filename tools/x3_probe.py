@@ -69,14 +69,6 @@ def probe_interleaved(M, N, K):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "km":
-        # K-tile-major weight addressing (dbg 32, timing only) against the row-major default
-        probe(98000, 256, 2304, conv=(500, 14, 256), res=False, shapes=(-1,), dbgs=(0, 32))
-        probe(392000, 128, 1152, conv=(500, 28, 128), res=False, shapes=(-1,), dbgs=(0, 32))
-        probe(24500, 512, 4608, conv=(500, 7, 512), res=False, shapes=(-1,), dbgs=(0, 32))
-        for M, N, K in [(392000, 512, 128), (98000, 1024, 256), (98000, 256, 1024), (392000, 128, 512), (24500, 2048, 512), (24500, 512, 2048)]:
-            probe(M, N, K, res=True, shapes=(-1,), dbgs=(0, 32))
-        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "il":
         shapes = [(98000, 256, 2304), (98000, 256, 1024), (24500, 512, 4608)]
         if len(sys.argv) > 2:
