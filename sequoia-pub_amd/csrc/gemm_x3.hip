@@ -197,6 +197,23 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
         for (int e = 0; e < 4; ++e) { scale8[e] = p.alpha * t0[e]; scale8[4 + e] = p.alpha * t1[e]; }
     }
 
+    // 128-row shape: the identity rows of the epilogue (HBM, the launch's largest read for an expand 1x1) are requested
+    // when the last K-tile's loads have been waited for, not when the epilogue needs them
+    const bool res_pre = BM_ == 128 && p.res != nullptr && e_live && !(p.dbg & 64);
+    constexpr int NPRE = BM_ == 128 ? ITER / 2 : 1;      // the first half of the rows (all of them spills)
+    u32x4 rpre_h[NPRE], rpre_l[NPRE];
+    auto prefetch_res = [&]() {
+        if constexpr (BM_ == 128) {
+            const bf16_t* rs = reinterpret_cast<const bf16_t*>(p.res);
+#pragma unroll
+            for (int it = 0; it < NPRE; ++it) {
+                const int m = min(m0 + e_rbase + it * RPI, p.M - 1);      // rows past M repeat the last one (never stored)
+                rpre_h[it] = *reinterpret_cast<const u32x4*>(rs + (long long)m * p.ldres + e_n);
+                rpre_l[it] = *reinterpret_cast<const u32x4*>(rs + p.plRes + (long long)m * p.ldres + e_n);
+            }
+        }
+    };
+
     f32x16 acc[WTM][WTN];
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
@@ -358,6 +375,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // tile kt landed everywhere; tile kt-1's buffer is free
             if (kt + 1 < nk) issue_loads(kt + 1, (kt + 1) & 1);
+            else if (res_pre) prefetch_res();           // behind the last counted wait: lands under the last tile's MFMAs and the stage dump
             compute(kt & 1);
         }
     }
@@ -382,6 +400,17 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
     bf16_t* ch = p.out_dtype != SQ_F32 ? reinterpret_cast<bf16_t*>(p.C) : nullptr;
     float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) : nullptr;
     constexpr int U = 4;
+    // with the first rows already in registers, the remaining ones are requested now and land under the first group's work
+    u32x4 nh[U], nl[U];
+    const bool res_nxt = res_pre && ITER == 2 * U && NPRE == U;
+    if (res_nxt) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = min(m0 + e_rbase + (U + u) * RPI, p.M - 1);
+            nh[u] = *reinterpret_cast<const u32x4*>(resh + (long long)m * p.ldres + e_n);
+            nl[u] = *reinterpret_cast<const u32x4*>(resh + p.plRes + (long long)m * p.ldres + e_n);
+        }
+    }
 #pragma unroll
     for (int c0 = 0; c0 < ITER; c0 += U) {
         // residual rows of a group are requested before that group's first store (vmcnt counts stores too)
@@ -390,6 +419,10 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
         for (int u = 0; u < U; ++u) {
             rh[u] = u32x4{0, 0, 0, 0}; rl[u] = u32x4{0, 0, 0, 0};
             const int m = m0 + e_rbase + (c0 + u) * RPI;
+            if constexpr (BM_ == 128) {
+                if (res_pre && c0 + u < NPRE) { rh[u] = rpre_h[c0 + u]; rl[u] = rpre_l[c0 + u]; continue; }
+                if (res_nxt && c0 == U) { rh[u] = nh[u]; rl[u] = nl[u]; continue; }
+            }
             if (resh && m < p.M) {
                 rh[u] = *reinterpret_cast<const u32x4*>(resh + (long long)m * p.ldres + e_n);
                 rl[u] = *reinterpret_cast<const u32x4*>(resh + p.plRes + (long long)m * p.ldres + e_n);

@@ -69,6 +69,11 @@ def probe_interleaved(M, N, K):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "res":
+        # identity rows requested under the last K-tile (default) against requested in the epilogue (dbg 64), 128-row shape
+        for M, N, K in [(784000, 512, 128), (196000, 1024, 256), (3136000, 256, 64), (392000, 512, 128), (98000, 1024, 256)]:
+            probe(M, N, K, res=True, shapes=(-1,), dbgs=(0, 64, 0, 64))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "il":
         shapes = [(98000, 256, 2304), (98000, 256, 1024), (24500, 512, 4608)]
         if len(sys.argv) > 2:
