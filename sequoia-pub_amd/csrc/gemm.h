@@ -54,6 +54,13 @@ struct GemmArgs {
     int vec_epi = 0;                   // set by sq_launch_gemm: all epilogue operands allow 16-byte accesses
     int b_tiled = 0;                   // split modes: B is K-tile-major -- element (n, k) at ((k / 32) * N + n) * 32 + k % 32 of its plane (K % 32 == 0):
                                        // a K-tile of BN rows is one contiguous run, every LDS-DMA request whole cache lines
+    // split modes, dual form (gemm_x3.hip): the identity of the epilogue is not read but computed in the launch as a second
+    // product, identity = join(split(colscale2 * (gather(A2) . B2^T) + bias2)) -- a bottleneck's downsample branch
+    // (src/resnet.py:87-88): row m = output pixel (img, oh, ow) reads the A2 row of input pixel (img, oh * s, ow * s)
+    const void* A2 = nullptr; long long plA2 = 0; size_t a2_bytes = 0; int lda2 = 0;   // NHWC input [n, dH, dW, K2] planes
+    const void* B2 = nullptr; size_t b2_bytes = 0; int ldb2 = 0; int K2 = 0;           // [N, K2] planes, plB apart, b_tiled as B
+    const float* bias2 = nullptr; const float* colscale2 = nullptr;
+    int dH = 0, dW = 0, dOH = 0, dOW = 0, dstride = 1;
     int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };
 

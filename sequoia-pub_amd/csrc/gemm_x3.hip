@@ -61,8 +61,9 @@ template <int BM_, int WTN> struct X3Cfg {
     static constexpr int LOADS = 4 + RB;                               // LDS-DMA instructions per thread per stage
 };
 
-template <int BM_, int WTN, bool CONV, bool F16, bool PP>
+template <int BM_, int WTN, bool CONV, bool F16, bool PP, bool DUAL = false>
 __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(const GemmArgs p) {
+    static_assert(!DUAL || (BM_ == 128 && !CONV && !PP), "the dual form lives in the 128-row two-stage shape");
     using Cfg = X3Cfg<BM_, WTN>;
     using Fmt = X3Fmt<F16>;
     constexpr int BM = Cfg::BM, NT = Cfg::NT, A_BYTES = Cfg::A_BYTES, ROUND = Cfg::ROUND;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             fb_off[j][s] = 2 * A_BYTES + row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4);
         }
     }
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, f32x16 (&acc)[WTM][WTN]) {
         const char* st = smem + buf * STAGE_BYTES;
         u32x4 ah[2][WTM], al[2][WTM], bh[2][WTN], bl[2][WTN];
 #pragma unroll
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             }
             __builtin_amdgcn_s_barrier();                   // everybody's part; and tile kt-1's buffer is free
             if (kt + 2 < nk) issue_loads(kt + 2, nxt2);
-            compute(cur);
+            compute(cur, acc);
             cur = cur == NSTAGE - 1 ? 0 : cur + 1;
             nxt2 = nxt2 == NSTAGE - 1 ? 0 : nxt2 + 1;
         }
@@ -376,7 +377,83 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             __builtin_amdgcn_s_barrier();                   // tile kt landed everywhere; tile kt-1's buffer is free
             if (kt + 1 < nk) issue_loads(kt + 1, (kt + 1) & 1);
             else if (res_pre) prefetch_res();           // behind the last counted wait: lands under the last tile's MFMAs and the stage dump
-            compute(kt & 1);
+            compute(kt & 1, acc);
+        }
+        if constexpr (DUAL) {
+            // ---- second product through the same two stages: identity = gather(A2) . B2^T (the downsample branch), joined
+            // with the first one in registers exactly as the two launches would be: the identity takes the stored planes'
+            // rounding, y = relu((acc * s3 + b3) + join(split(accd * sd + bd))) -- the downsample tensor is neither written nor read
+            __syncthreads();                            // every wave has read the first product's last tile
+            const bf16_t* A2h = reinterpret_cast<const bf16_t*>(p.A2);
+            const bf16_t* B2h = reinterpret_cast<const bf16_t*>(p.B2);
+            const auto rsXh = __builtin_amdgcn_make_buffer_rsrc((void*)A2h, 0, (int)p.a2_bytes, 0x00020000);
+            const auto rsXl = __builtin_amdgcn_make_buffer_rsrc((void*)(A2h + p.plA2), 0, (int)p.a2_bytes, 0x00020000);
+            const auto rsDh = __builtin_amdgcn_make_buffer_rsrc((void*)B2h, 0, (int)p.b2_bytes, 0x00020000);
+            const auto rsDl = __builtin_amdgcn_make_buffer_rsrc((void*)(B2h + p.plB), 0, (int)p.b2_bytes, 0x00020000);
+            uint32_t x_off[2], d_off[RBP];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = m0 + r0 + ROUND * j;
+                const int ohw = p.dOH * p.dOW;
+                const int img = m / ohw, rem = m - img * ohw, oh = rem / p.dOW, ow = rem - oh * p.dOW;
+                const uint32_t pix = (uint32_t)((img * p.dH + oh * p.dstride) * p.dW + ow * p.dstride);
+                x_off[j] = m < p.M ? (pix * (uint32_t)p.lda2 + (uint32_t)(gc * 8)) * 2u : OOB;
+            }
+#pragma unroll
+            for (int j = 0; j < RBP; ++j) {
+                const int n = n0 + (Cfg::SPLIT_B ? (r0 & 63) : r0 + ROUND * j);
+                d_off[j] = n >= p.N ? OOB : p.b_tiled ? ((uint32_t)n * 32u + (uint32_t)(gc * 8)) * 2u : ((uint32_t)n * (uint32_t)p.ldb2 + (uint32_t)(gc * 8)) * 2u;
+            }
+            auto issue2 = [&](int kt, int buf) {
+                char* sa = smem + buf * STAGE_BYTES + wave * 1024;
+                char* sb = sa + 2 * A_BYTES;
+                const int soff = kt * BK * 2, soffb = p.b_tiled ? kt * p.N * 64 : soff;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    glds16(rsXh, sa + j * (ROUND * ROWB), x_off[j], soff);
+                    glds16(rsXl, sa + A_BYTES + j * (ROUND * ROWB), x_off[j], soff);
+                }
+#pragma unroll
+                for (int j = 0; j < RBP; ++j) {
+                    if constexpr (Cfg::SPLIT_B) {
+                        if (b_lo_half) glds16(rsDl, sb, d_off[j], soffb); else glds16(rsDh, sb, d_off[j], soffb);
+                    } else {
+                        glds16(rsDh, sb + j * (ROUND * ROWB), d_off[j], soffb);
+                        glds16(rsDl, sb + B_BYTES + j * (ROUND * ROWB), d_off[j], soffb);
+                    }
+                }
+            };
+            f32x16 accd[WTM][WTN];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) accd[i][j][e] = 0.f;
+            const int nk2 = p.K2 / BK;
+            issue2(0, 0);
+            for (int kt = 0; kt < nk2; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < nk2) issue2(kt + 1, (kt + 1) & 1);
+                compute(kt & 1, accd);
+            }
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                const int col = min(n0 + wn * (WTN * 32) + j * 32 + l31, p.N - 1);
+                const float s3 = p.colscale ? p.alpha * p.colscale[col] : p.alpha, b3 = p.bias ? p.bias[col] : 0.f;
+                const float sd = p.colscale2 ? p.colscale2[col] : 1.f, bd = p.bias2 ? p.bias2[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float d0 = sd * accd[i][j][r] + bd, d1 = sd * accd[i][j][r + 1] + bd;
+                        const uint32_t h = Fmt::pack2(d0, d1);
+                        const uint32_t l = Fmt::pack2(d0 - Fmt::lo_f(h), d1 - Fmt::hi_f(h));
+                        acc[i][j][r] = fmaxf((s3 * acc[i][j][r] + b3) + (Fmt::lo_f(h) + Fmt::lo_f(l)), 0.f);
+                        acc[i][j][r + 1] = fmaxf((s3 * acc[i][j][r + 1] + b3) + (Fmt::hi_f(h) + Fmt::hi_f(l)), 0.f);
+                    }
+            }
         }
     }
     __syncthreads();                                    // all MFMAs read their fragments: the ring becomes the fp32 stage
@@ -436,6 +513,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8 + 4);
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            if constexpr (!DUAL) {                 // (dual form: the stage already holds the finished values)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = scale8[e] * v[e] + bias8[e];
             if (resh) {
@@ -447,6 +525,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             if (p.act == SQ_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
             }
             if (p.dbg & 1) continue;
             if (c32) {
@@ -481,6 +560,20 @@ int launch_x3(const GemmArgs& a, hipStream_t stream) {
     return SQ_OK;
 }
 
+template <bool F16>
+int launch_x3_dual(const GemmArgs& a, hipStream_t stream) {
+    using Cfg = X3Cfg<128, 2>;
+    static bool attr = false;
+    if (!attr) {
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<128, 2, false, F16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr = true;
+    }
+    const int tiles = ((a.M + 127) / 128) * (a.N / Cfg::BN);
+    hipLaunchKernelGGL((gemm_x3_kernel<128, 2, false, F16, false, true>), dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, a);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
 template <int BM_, bool PP>
 int launch_x3_fmt(const GemmArgs& a, hipStream_t stream) {
     if (a.x3_f16) return a.N % 128 == 0 ? launch_x3<BM_, 2, true, PP>(a, stream) : launch_x3<BM_, 1, true, PP>(a, stream);
@@ -509,8 +602,21 @@ int sq_launch_gemm_x3(const GemmArgs& a_in, hipStream_t stream) {
     SQ_REQUIRE(!a.b_tiled || a.K % BK == 0, "gemm_x3: K-tile-major weights need K %% %d == 0 (K=%d)", BK, a.K);
     if (a.conv) SQ_REQUIRE(a.Cin % BK == 0, "conv_x3: Cin=%d must be a multiple of the K-tile (%d)", a.Cin, BK);
     else SQ_REQUIRE(a.lda % 8 == 0, "gemm_x3: lda=%d must be a multiple of 8", a.lda);
+    const bool dual = a.A2 != nullptr;
+    if (dual) {
+        SQ_REQUIRE(!a.conv && !a.res && a.act == SQ_ACT_RELU && a.N % 128 == 0 && a.out_dtype != SQ_F32, "gemm_x3 dual: plain product, no residual, ReLU, N %% 128 == 0, plane output");
+        SQ_REQUIRE(a.B2 && a.K2 > 0 && a.K2 % BK == 0 && a.lda2 % 8 == 0 && a.plA2 != 0 && (a.plA2 & 7) == 0 && ((uintptr_t)a.A2 & 15) == 0 && ((uintptr_t)a.B2 & 15) == 0,
+                   "gemm_x3 dual: second operand pair (K2=%d)", a.K2);
+        SQ_REQUIRE(a.a2_bytes > 0 && a.a2_bytes < (1ull << 31) && a.b2_bytes > 0 && a.b2_bytes < (1ull << 31) && (a.b_tiled || a.ldb2 % 8 == 0), "gemm_x3 dual: operand extents");
+        SQ_REQUIRE(a.dOH > 0 && a.dOW > 0 && a.M % (a.dOH * a.dOW) == 0 && a.dstride >= 1 && (a.dOH - 1) * a.dstride < a.dH && (a.dOW - 1) * a.dstride < a.dW,
+                   "gemm_x3 dual: gather geometry %dx%d -> %dx%d stride %d", a.dH, a.dW, a.dOH, a.dOW, a.dstride);
+    }
     int prof = -1;
-    if (sq_prof_on()) {
+    if (sq_prof_on() && dual) {
+        char name[96];
+        snprintf(name, sizeof(name), "dual_%s_M%d_N%d_K%d_K%d", a.x3_f16 ? "f16x3" : "bf16x3", a.M, a.N, a.K, a.K2);
+        prof = sq_prof_begin(name, 2.0 * a.M * (double)a.N * (a.K + a.K2), ((double)a.M * (a.K + a.K2) + (double)a.N * (a.K + a.K2)) * 4.0 + (double)a.M * a.N * 4.0, stream);
+    } else if (sq_prof_on()) {
         const double flops = 2.0 * a.M * (double)a.N * a.K;      // algorithmic (fp32-equivalent) work; the kernel issues 3x that in bf16 MFMAs
         const double a_elems = a.conv ? (double)a.M / (a.OH * a.OW) * a.H * a.W * a.Cin : (double)a.M * a.K;
         const double bytes = (a_elems + (double)a.N * a.K) * 4.0 + (double)a.M * a.N * (4.0 + (a.res ? 4.0 : 0.0));
@@ -522,7 +628,8 @@ int sq_launch_gemm_x3(const GemmArgs& a_in, hipStream_t stream) {
     static int env_max_k = -1;                                       // products with K up to this take the 128-row, two-blocks-per-CU shape
     if (env_max_k < 0) { const char* e = getenv("SQ_X3_SMALL_MAXK"); env_max_k = e ? atoi(e) : 256; }
     const int small_max_k = g_x3_small_max_k >= 0 ? g_x3_small_max_k : env_max_k;
-    const int rc = (g_x3_halo != 0 && sq_conv_halo_x3_eligible(a)) ? sq_launch_conv_halo_x3(a, stream)
+    const int rc = dual ? (a.x3_f16 ? launch_x3_dual<true>(a, stream) : launch_x3_dual<false>(a, stream))
+                 : (g_x3_halo != 0 && sq_conv_halo_x3_eligible(a)) ? sq_launch_conv_halo_x3(a, stream)
                  : (a.K <= small_max_k || (a.N <= 64 && small_max_k > 0)) ? launch_x3_fmt<128, false>(a, stream)
                  : lockstep ? launch_x3_fmt<256, false>(a, stream) : launch_x3_fmt<256, true>(a, stream);
     if (prof >= 0) sq_prof_end(prof, stream);

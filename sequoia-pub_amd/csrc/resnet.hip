@@ -269,7 +269,10 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                "resnet50: sub-batch of %d patches exceeds the 2 GiB buffer-descriptor limit (bf16 and the split modes: <= 1300 patches of 224, fp32: <= 280)", n);
 
     // conv as a GEMM launch.  in: NHWC [n, H, H, cin];  out: [n, OH, OH, cout]
-    auto conv = [&](const sq_conv_desc& d, const void* in, int H, void* out, int OH, const void* res, int act) -> int {
+    // dual (split modes): the block's downsample branch dd(din) -- din = the block's input [n, dH, dH, dd.cin] -- rides in the
+    // expand launch as a second product instead of being written and read back as `res` (gemm.h A2 / B2)
+    auto conv = [&](const sq_conv_desc& d, const void* in, int H, void* out, int OH, const void* res, int act,
+                    const sq_conv_desc* dd = nullptr, const void* din = nullptr, int dH = 0) -> int {
         GemmArgs g;
         g.M = n * OH * OH; g.N = d.cout; g.K = d.k_padded;
         g.A = in;
@@ -288,6 +291,12 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
             g.plA = act_plane; g.plC = act_plane; g.plRes = act_plane; g.plB = lay.w_total;
             g.x3_f16 = f16; g.colscale = colscale + d.b_off;
             g.b_tiled = 1;             // every convolution behind the stem: K-tile-major planes (resnet.py split_planes)
+            if (dd) {
+                g.A2 = din; g.plA2 = act_plane; g.lda2 = dd->cin; g.a2_bytes = (size_t)n * dH * dH * dd->cin * es;
+                g.B2 = W(*dd); g.ldb2 = dd->k_padded; g.b2_bytes = w_bytes_total - (size_t)dd->w_off * es; g.K2 = dd->k_padded;
+                g.bias2 = bias + dd->b_off; g.colscale2 = colscale + dd->b_off;
+                g.dH = dH; g.dW = dH; g.dOH = OH; g.dOW = OH; g.dstride = dd->stride;
+            }
             return sq_launch_gemm_x3(g, st);
         }
         return sq_launch_gemm(g, dtype, st);
@@ -393,7 +402,10 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                 continue;
             }
             const void* identity = x;
-            if (has_ds) {
+            // split modes: the downsample branch of layers 2-4 (1x1, stride 2) as a second product of the expand launch
+            // (SQ_RESNET_NO_DUAL=1: its own launch, a [n, OH, OH, 4 planes] tensor written and read back)
+            const bool x3_dual = x3 && has_ds && lay.conv[ci + 3].k == 1 && c3.k == 1 && c3.cout % 128 == 0 && !sq_env_flag("SQ_RESNET_NO_DUAL");
+            if (has_ds && !x3_dual) {
                 RUN(conv(lay.conv[ci + 3], x, H, ds, OH, nullptr, SQ_ACT_NONE));
                 identity = ds;
             }
@@ -426,7 +438,8 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
                 H = OH;
                 continue;
             }
-            RUN(conv(c3, t2, OH, y, OH, identity, SQ_ACT_RELU));       // relu(bn3(conv3) + identity)
+            if (x3_dual) RUN(conv(c3, t2, OH, y, OH, nullptr, SQ_ACT_RELU, &lay.conv[ci + 3], x, H));
+            else RUN(conv(c3, t2, OH, y, OH, identity, SQ_ACT_RELU));       // relu(bn3(conv3) + identity)
             ci = cnext;
             xi = free_[2];
             t1i = -1;

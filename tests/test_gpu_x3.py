@@ -216,20 +216,22 @@ def test_resnet50_x3_fused_chain_is_bit_identical(monkeypatch, mode):
     1x1 in one launch, t2 and y handed over through LDS) walks K in the same order with the same MFMA sequence and epilogue
     arithmetic as the gemm_x3.hip / conv_halo_x3.hip launches it replaces: the features must not change by a bit.
     SQ_RESNET_NO_TAIL=1: the 3x3 as its own launch; SQ_RESNET_NO_CHAIN_DS=1: the downsample branch too; SQ_RESNET_NO_CHAIN=1:
-    nothing fused."""
+    nothing fused in the 56 x 56 stage.  The downsample branches of layers 2-4 (and of layer 1 when the chain is off) ride in the
+    expand launch as a second product (gemm_x3.hip dual form) unless SQ_RESNET_NO_DUAL=1: same requirement."""
     _lib.require_gpu()
     m, sd = _model(mode)
     p = torch.from_numpy(synth.patches_u8(5, n_patches=3, size=224)).cuda()
     p256 = torch.from_numpy(synth.patches_u8(6, n_patches=1, size=256)).cuda()          # 64 x 64 maps: wider than the tail form takes
     outs = {}
     for tag, env in (("tail", {}), ("chain", {"SQ_RESNET_NO_TAIL": "1"}), ("chain_no_ds", {"SQ_RESNET_NO_TAIL": "1", "SQ_RESNET_NO_CHAIN_DS": "1"}),
-                     ("plain", {"SQ_RESNET_NO_CHAIN": "1"})):
-        for k in ("SQ_RESNET_NO_TAIL", "SQ_RESNET_NO_CHAIN_DS", "SQ_RESNET_NO_CHAIN"):
+                     ("no_dual", {"SQ_RESNET_NO_DUAL": "1"}), ("dual_everywhere", {"SQ_RESNET_NO_CHAIN": "1"}),
+                     ("plain", {"SQ_RESNET_NO_CHAIN": "1", "SQ_RESNET_NO_DUAL": "1"})):
+        for k in ("SQ_RESNET_NO_TAIL", "SQ_RESNET_NO_CHAIN_DS", "SQ_RESNET_NO_CHAIN", "SQ_RESNET_NO_DUAL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         outs[tag] = (m.extract_patches_u8(p), m.extract_patches_u8(p256))
     torch.cuda.synchronize()
     assert torch.isfinite(outs["tail"][0]).all()
-    for tag in ("tail", "chain", "chain_no_ds"):
+    for tag in ("tail", "chain", "chain_no_ds", "no_dual", "dual_everywhere"):
         assert torch.equal(outs[tag][0], outs["plain"][0]) and torch.equal(outs[tag][1], outs["plain"][1]), tag
