@@ -23,15 +23,17 @@ for w in pipe pipe_serial train train_serial; do
   [ -n "$f" ] && cp $f gpurun_out/profiles_r03/$t
 done
 python tools/pmc_summary.py r03_pipeline_f16x3 gpurun_out/profiles_r03/r03_pipeline_f16x3_pmc.json $O/pmc_pipe_FETCH_SIZE $O/pmc_pipe_WRITE_SIZE $O/pmc_pipe_SQ_VALU_MFMA_BUSY_CYCLES \
-  "gemm_f16x3_M196000_N1024_K256=gemm_x3_kernel<128, 2, false, true, false>:3137536" \
-  "gemm_f16x3_M784000_N512_K128=gemm_x3_kernel<128, 2, false, true, false>:6272000" \
-  "gemm_f16x3_M196000_N256_K1024=gemm_x3_kernel<256, 2, false, true, true>:784384" \
+  "gemm_f16x3_M196000_N1024_K256=gemm_x3_kernel<128, 2, false, true, false, false>:3137536" \
+  "gemm_f16x3_M784000_N512_K128=gemm_x3_kernel<128, 2, false, true, false, false>:6272000" \
+  "gemm_f16x3_M196000_N256_K1024=gemm_x3_kernel<256, 2, false, true, true, false>:784384" \
   "conv_f16x3_M196000_N256_K2304=conv_halo_x3_kernel<2, 320, true, true>:784384" \
   "conv_f16x3_M784000_N128_K1152=conv_halo_x3_kernel<2, 320, true, true>:1568256" \
   "conv_f16x3_M49000_N512_K4608=conv_halo_x3_kernel<2, 320, true, true>:393216" \
   "tail_f16x3_c64_cn64_P3136000=chain_x3_kernel<64, true, false, true>:12544000" \
   "tail_f16x3_c64_cn64_ds_P3136000=chain_x3_kernel<64, true, true, true>:12544000" \
   "tail_f16x3_c64_cn128_P3136000=chain_x3_kernel<128, true, false, true>:12544000" \
+  "dual_f16x3_M784000_N512_K128_K256=gemm_x3_kernel<128, 2, false, true, false, true>:6272000" \
+  "dual_f16x3_M196000_N1024_K256_K512=gemm_x3_kernel<128, 2, false, true, false, true>:3137536" \
   "conv1_pool_f16x3=conv1_pool_x3_kernel<true>:131072"
 python tools/pmc_summary.py r03_vis_train_bf16 gpurun_out/profiles_r03/r03_vis_train_bf16_pmc.json $O/pmc_train_FETCH_SIZE $O/pmc_train_WRITE_SIZE $O/pmc_train_SQ_VALU_MFMA_BUSY_CYCLES \
   "gemm_bf16_M6400_N1024_K1024_b1=gemm_nt_kernel<unsigned short, 2, 2, false:102400" \
