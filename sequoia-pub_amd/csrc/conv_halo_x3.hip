@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
     }
     const int p0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
     const int W = p.W, HWp = p.H * p.W, C = p.Cin;
-    const int ncb = C / CB;
+    const int ncb = (p.dbg & 4) ? 0 : (C / CB);        // dbg 4 (x3_probe.py halo): no K loop -- what a tile costs around it
     const int halo0 = p0 - W - 1;
     const int halo_slots = (BM + 2 * W + 2) * 4;  // per plane
 
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
     for (int u = 0; u < ITER; ++u) {
         const int row = e_rbase + u * RPI;
         const int m = p0 + row;
-        if (m >= p.M) continue;
+        if (m >= p.M || (p.dbg & 1)) continue;             // dbg 1: no epilogue work per row, no stores
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * BN + e_c8 * 8 + 4);
         float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};

@@ -69,6 +69,12 @@ def probe_interleaved(M, N, K):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "halo":
+        # per-tile fixed cost of the halo-staged 3x3: the three stages' shapes with stores / loads switched off
+        probe(784000, 128, 1152, conv=(1000, 28, 128), res=False, shapes=(-1,), dbgs=(0, 0, 1, 4, 5))
+        probe(196000, 256, 2304, conv=(1000, 14, 256), res=False, shapes=(-1,), dbgs=(0, 0, 1, 4, 5))
+        probe(49000, 512, 4608, conv=(1000, 7, 512), res=False, shapes=(-1,), dbgs=(0, 0, 1, 4, 5))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "res":
         # identity rows requested under the last K-tile (default) against requested in the epilogue (dbg 64), 128-row shape
         for M, N, K in [(784000, 512, 128), (196000, 1024, 256), (3136000, 256, 64), (392000, 512, 128), (98000, 1024, 256)]:
