@@ -129,10 +129,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_w4_kernel(const GemmArgs p) {
                 const uint32_t off = ((a_pix[j] + (uint32_t)(ih * p.W + iw)) * (uint32_t)p.Cin + (uint32_t)l_cin0) * 2u;
                 glds16(rsA, sa + j * (ROUND * ROWB), ok ? off : OOB, 0);
             } else {
+                if (p.dbg & 64) {    // ... and K-tile-major activations, timing only
+                    const int m = m0 + r0 + ROUND * j;
+                    glds16(rsA, sa + j * (ROUND * ROWB), l_kok && m < p.M ? ((uint32_t)m * 32u + (uint32_t)(gc * 8)) * 2u : OOB, (l_k0 >> 5) * p.M * 64);
+                } else
                 glds16(rsA, sa + j * (ROUND * ROWB), l_kok ? a_off[j] : OOB, l_k0 * 2);
             }
         } else {
             const int j = which - RA;
+            if (p.dbg & 32) {        // gemm_probe.py w4t: K-tile-major weights (element (n, k) at ((k / 32) * N + n) * 32 + k % 32), timing only
+                const int n = n0 + r0 + ROUND * j;
+                glds16(rsB, sa + BM * ROWB + j * (ROUND * ROWB), l_kok && n < p.N ? ((uint32_t)n * 32u + (uint32_t)(gc * 8)) * 2u : OOB, (l_k0 >> 5) * p.N * 64);
+            } else
             glds16(rsB, sa + BM * ROWB + j * (ROUND * ROWB), l_kok ? b_off[j] : OOB, l_k0 * 2);
         }
     };

@@ -54,6 +54,11 @@ if __name__ == "__main__":
         for M, N, K in [(8192, 8192, 8192), (102400, 1024, 1024), (98000, 1024, 256), (98000, 512, 1024), (24500, 2048, 512), (392000, 512, 128), (98000, 256, 1024), (392000, 128, 512)]:
             probe(M, N, K, _lib.SQ_BF16, tiles=(22, 44), dbgs=(0,))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "w4t":
+        # gemm_w4.hip with K-tile-major operand addressing (dbg 32: weights, 96: weights and activations), timing only
+        for M, N, K in [(8192, 8192, 8192), (102400, 1024, 1024), (50432, 4096, 1024), (50432, 1024, 4096), (50432, 3072, 1024), (102400, 2048, 2048)]:
+            probe(M, N, K, _lib.SQ_BF16, tiles=(55,), dbgs=(0, 32, 96, 0, 32, 96))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "w4":
         for M, N, K in [(8192, 8192, 8192), (4096, 4096, 4096), (102400, 1024, 1024), (50432, 4096, 1024), (50432, 1024, 4096), (24500, 512, 4608),
                         (24500, 2048, 1024), (98000, 1024, 512), (98000, 512, 1024), (6400, 1024, 1024)]:
