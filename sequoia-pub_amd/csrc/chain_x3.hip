@@ -9,20 +9,24 @@
 // (1 KB) and t1' (256 / 512 B) written -- 2.5 KB instead of 3.75 KB, and two launches become one.
 //
 // Tile = 64 pixels x all 256 channels, 4 waves, 80 KiB of LDS, TWO blocks per CU (one block's memory phases run under the
-// other's matrix phases):
-//   1. both 32-deep K-tiles of t2 (8 KiB) and w3 (64 KiB) arrive by LDS-DMA at once (K = 64: no ring);
-//      wave w multiplies pixels x channels [64 w, 64 w + 64): 48 MFMAs;
-//   2. the fp32 tile goes to LDS (64 KiB, over the operand buffers) in 32-byte chunks of 8 channels whose position in the
-//      1 KiB row is XOR-ed with the row index; the epilogue thread of a chunk adds bias / identity, applies ReLU, stores
+// other's matrix phases).  All weights are read from fragment-ordered copies that a pack kernel writes in front of the
+// launch (bottom of this file): every wave-wide weight request is one contiguous 1 KiB.
+//   1. both 32-deep K-tiles of t2 (8 KiB) arrive by LDS-DMA; the B fragments of w3 (no other wave reads a wave's 64 rows)
+//      go straight from L2 into registers; wave w multiplies pixels x channels [64 w, 64 w + 64): 48 MFMAs;
+//   2. the fp32 tile goes to LDS (64 KiB) in 32-byte chunks of 8 channels whose position in the 1 KiB row is XOR-ed with
+//      the row index; the epilogue thread of a chunk adds bias / identity (requested long before), applies ReLU, stores
 //      the y planes (512-byte runs per row and plane) and writes hi (16 B) + lo (16 B) back INTO ITS OWN 32 bytes -- the
 //      row-XOR makes exactly that image conflict-free for the A-fragment reads of the second product;
-//   3. t1' = y . w1'^T with A from LDS and the B fragments (w1', L2-resident) loaded straight into registers, four k-steps
-//      ahead, every fragment by one wave (a persistent form that keeps w1' in registers spills: 128 VGPRs beside the first
-//      product's accumulators -- measured 1.6x slower);
+//   3. t1' = y . w1'^T with A from LDS and the B fragments (w1', L2-resident) in registers, requested before the first
+//      epilogue (every fragment by one wave);
 //   4. t1' through a small fp32 stage (over the dead y image) -> scale / bias / ReLU -> planes.
+// Downsample form (first block of the stage): the identity x . wd^T is a second 64-deep product (x tile by LDS-DMA behind
+// the first product's A tile, wd fragments in registers), joined in registers with the rounding the stored planes would have.
 // Tail form: the block's 3x3 convolution (64 -> 64) runs in front of step 1 on the same tile -- the 64 + 2 W + 2 input rows of
-// both 32-channel blocks resident in LDS (48 KiB), weights through a three-stage ring -- and hands t2 to the first product
-// through LDS: t2 is neither written nor read, and the 3x3's matrix work hides under the launch's memory phases.
+// both 32-channel blocks resident in LDS (48 KiB), weights through a four-stage ring of contiguous 8 KiB tiles -- and hands t2
+// to the first product through LDS: t2 is neither written nor read.  The w3 / wd fragments and the identity rows are
+// requested four at a time behind the first eight 3x3 steps (vmcnt retires in order; the counted waits of the ring allow
+// for them).
 // Same K order, same MFMA order per accumulator and the same epilogue arithmetic as the gemm_x3.hip / conv_halo_x3.hip
 // launches it replaces: bit-identical results (tests/test_gpu_x3.py).
 #include "gemm.h"
