@@ -220,7 +220,7 @@ int sq_kmeans_fit(const float* X, int n_slides, int n_samples, int dim, int n_cl
  * dtype SQ_DTYPE_BF16X3 / SQ_DTYPE_F16X3: `weights` = the 16-bit hi plane [w_total] followed by the lo plane [w_total]
  * (hi = cvt(w'), lo = cvt(w' - hi)) of the packed fp32 weights w' = w * s[cout], and `bias` = [b_total] biases followed by
  * [b_total] per-output-channel factors 1 / s (at the same b_off): s = 1 for bf16 planes; for fp16 planes a power of two
- * that lifts each weight row to max |w'| in [256, 512) so that the lo plane stays in fp16's normal range.
+ * that lifts each weight row to max |w'| in (128, 256] so that the lo plane stays in fp16's normal range.
  * In these two dtypes every convolution behind the stem (i >= 1) is stored K-TILE-MAJOR inside its block of either plane:
  * element (n, k) of [cout][k_padded] at w_off + ((k / 32) * cout + n) * 32 + k % 32 (k_padded % 32 == 0 for all of them), so
  * that a 32-deep K-tile of consecutive output channels is one contiguous run; conv 0 keeps [64][152] rows.

@@ -66,7 +66,7 @@ def pack_weights(sd, lay=None):
 def split_planes(w, b, dtype, lay=None):
     """Packed fp32 weights / biases -> what sq_resnet50_extract takes in the split modes: 16-bit hi plane followed by the
     lo plane (hi = cvt(w'), lo = cvt(w' - hi)), and biases followed by the per-output-channel factors that undo w' = w * s.
-    bf16 planes: s = 1.  fp16 planes: s = the power of two that lifts the row's max |w| into [256, 512), so the lo plane
+    bf16 planes: s = 1.  fp16 planes: s = the power of two that lifts the row's max |w| into (128, 256], so the lo plane
     (<= 2^-12 of the value) stays in fp16's normal range for every weight that matters in its row."""
     lay = lay or resnet50_layout()
     scale = torch.ones_like(b)

@@ -71,3 +71,37 @@ def test_model_without_gpu_raises_not_falls_back():
     m = ViS(8, 64, 1, 1, 64, 64, 64, device="cpu")
     with pytest.raises(_lib.SequoiaHipError):
         m(torch.zeros(1, 100, 64))
+
+
+def test_split_planes_layout_matches_the_header():
+    """include/sequoia_hip.h, split modes: weights = hi plane [w_total] then lo plane [w_total]; every convolution behind the
+    stem K-tile-major inside its block -- element (n, k) at w_off + ((k // 32) * cout + n) * 32 + k % 32 -- the stem row-major;
+    bias = [b_total] biases then [b_total] per-channel factors that undo the power-of-two pre-scaling (host logic, no GPU)."""
+    import torch
+    from sequoia_pub_amd import resnet as rn
+    lay = rn.resnet50_layout()
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(lay.w_total, generator=g) * 0.05
+    b = torch.randn(lay.b_total, generator=g)
+    planes, bs = rn.split_planes(w, b, _lib.SQ_F16X3, lay)
+    assert planes.numel() == 2 * lay.w_total and bs.numel() == 2 * lay.b_total
+    hi = planes[:lay.w_total].view(torch.float16).float()
+    lo = planes[lay.w_total:].view(torch.float16).float()
+    scale = bs[lay.b_total:]
+    assert torch.equal(bs[:lay.b_total], b)
+    for i in (0, 1, 2, 4, 14, 52):
+        d = lay.conv[i]
+        K = d.k_padded
+        rows = w[d.w_off:d.w_off + d.cout * K].view(d.cout, K)
+        s = 1.0 / scale[d.b_off:d.b_off + d.cout]                  # the power of two each row was multiplied by
+        assert torch.equal(torch.exp2(torch.round(torch.log2(s))), s)
+        amax = (rows * s[:, None]).abs().amax(dim=1)
+        assert bool(((amax > 128) & (amax <= 256)).all())
+        got = (hi + lo)[d.w_off:d.w_off + d.cout * K]
+        if i == 0:
+            back = got.view(d.cout, K)                             # stem: [64][152] rows
+        else:
+            assert K % 32 == 0
+            back = got.view(K // 32, d.cout, 32).permute(1, 0, 2).reshape(d.cout, K)
+        # hi + lo carries 22 bits of the scaled weight
+        assert torch.allclose(back / s[:, None], rows, rtol=3e-7, atol=1e-9)
