@@ -69,6 +69,11 @@ def probe_interleaved(M, N, K):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "add":
+        # do the memory time and the matrix time of an HBM-bound expand add up?  (dbg 4 no MFMA, 1 no stores, 8 no fragment reads)
+        for M, N, K in [(784000, 512, 128), (196000, 1024, 256)]:
+            probe(M, N, K, res=True, shapes=(-1,), dbgs=(0, 0, 4, 12, 1, 5, 13))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "halo":
         # per-tile fixed cost of the halo-staged 3x3: the three stages' shapes with stores / loads switched off
         probe(784000, 128, 1152, conv=(1000, 28, 128), res=False, shapes=(-1,), dbgs=(0, 0, 1, 4, 5))
