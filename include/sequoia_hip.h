@@ -29,7 +29,7 @@ typedef void* sq_event_t;  /* hipEvent_t */
 #define SQ_DTYPE_BF16X3 2 /* split bf16 (sq_resnet50_extract only): every fp32 value as hi + lo bf16 planes, a.b = a_hi.b_hi + a_hi.b_lo +
                              a_lo.b_hi on bf16 MFMAs with fp32 accumulation -- 2^-18 per operand, fp32's exponent range */
 #define SQ_DTYPE_F16X3 3  /* the same with fp16 planes: 22 significant bits (fp32-class results), values must stay below 65504
-                             (an overflow propagates to the features as inf / NaN); the fast parity mode */
+                             (an overflow propagates to the features as NaN and raises sq_resnet50_extract_checked's flag); the fast parity mode */
 
 #define SQ_MAX_DEPTH 16
 #define SQ_HEAD_DIM 64 /* dimensions_f = dimensions_s = dimensions_c = 64 (src/main.py:147,167,202) */
@@ -242,6 +242,14 @@ size_t sq_resnet50_workspace_bytes(int dtype, int n_patches, int patch_size);
 int sq_resnet50_extract(int dtype, const void* weights, const float* bias, const uint8_t* patches_u8,
                         const float* patches_f32_nchw, int n_patches, int patch_size, float* features,
                         void* workspace, size_t workspace_bytes, sq_stream_t stream);
+/* The same, with a guard for the reduced range of SQ_DTYPE_F16X3: nonfinite_flag (device word, caller-zeroed, may be NULL)
+ * gets bit 0 OR-ed in when any pooled feature of this call is not finite.  An activation >= 65504 anywhere in the network
+ * becomes inf planes, NaN in the next product, and the split modes' ReLU lets NaN through (csrc/x3_fmt.h), so every such
+ * overflow reaches the features and the flag; the caller re-runs those patches in SQ_DTYPE_F32 (resnet.py does).
+ * The reference computes src/resnet.py:155-170 in fp32, where this cannot happen below 3.4e38. */
+int sq_resnet50_extract_checked(int dtype, const void* weights, const float* bias, const uint8_t* patches_u8,
+                                const float* patches_f32_nchw, int n_patches, int patch_size, float* features,
+                                void* workspace, size_t workspace_bytes, uint32_t* nonfinite_flag, sq_stream_t stream);
 
 /* dst_bf16[i] = bf16(src[i]) -- refresh of the bf16 parameter shadow after an optimizer step */
 int sq_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, sq_stream_t stream);

@@ -114,3 +114,57 @@ def embed_patches(sd, patches_u8, batch=1):
         for i in range(0, len(patches_u8), batch):
             outs.append(forward_extract(sd, transform_patch_u8(patches_u8[i:i + batch])))
     return torch.cat(outs, 0)
+
+
+def init_resnet50_state_dict_wide(seed, running_stats=None):
+    """A weight set with the dynamic range of a trained network instead of He-init's flat one: every output channel's
+    weight row is multiplied by m_c (log-uniform over 10^-1.5 .. 10^0.5) and BN gamma is log-uniform over 0.1 .. 10, beta =
+    0.2 gamma N(0,1).  The running statistics are what BatchNorm would have tracked for these weights -- calibrated by
+    ``calibrate_bn`` on a batch of patches and kept as data (``running_stats``: name -> tensor; tests/golden/
+    resnet50_wide_bn.npz) -- so running_var spans ~4 decades (~ m_c^2) and the folded scale gamma / sqrt(var) ~5, while the
+    activations stay in the range a trained network produces (per-channel std = gamma).  Without ``running_stats`` the
+    statistics are mean 0 / var 1 placeholders."""
+    g = torch.Generator().manual_seed(seed)
+    sd = init_resnet50_state_dict(seed=seed + 1, perturb_bn=False)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            name = k[:-len(".running_mean")]
+            c = sd[k].numel()
+            conv = name.replace("bn", "conv") if "downsample" not in name else name[:-1] + "0"
+            m = torch.pow(10.0, -1.5 + 2.0 * torch.rand(c, generator=g))
+            sd[conv + ".weight"] = sd[conv + ".weight"] * m.view(-1, 1, 1, 1)
+            gamma = torch.pow(10.0, -1.0 + 2.0 * torch.rand(c, generator=g))
+            sd[name + ".weight"] = gamma
+            sd[name + ".bias"] = 0.2 * gamma * torch.randn(c, generator=g)
+            if running_stats is not None:
+                sd[name + ".running_mean"] = torch.as_tensor(running_stats[name + ".running_mean"]).float().clone()
+                sd[name + ".running_var"] = torch.as_tensor(running_stats[name + ".running_var"]).float().clone()
+    return sd
+
+
+def calibrate_bn(sd, x):
+    """Set every BN's running_mean / running_var to the batch statistics (biased variance over N, H, W) its input has when
+    ``x`` (f32 [n, 3, H, W], normalised) flows through the network layer by layer -- what train-mode BN converges to.
+    Returns the statistics as a dict of numpy arrays (the fixture)."""
+    stats = {}
+
+    def bn(name, y):
+        mean = y.mean(dim=(0, 2, 3))
+        var = y.var(dim=(0, 2, 3), unbiased=False)
+        sd[name + ".running_mean"], sd[name + ".running_var"] = mean, var
+        stats[name + ".running_mean"], stats[name + ".running_var"] = mean.numpy().copy(), var.numpy().copy()
+        return _bn(sd, name, y)
+
+    with torch.no_grad():
+        x = F.max_pool2d(F.relu(bn("bn1", F.conv2d(x, sd["conv1.weight"], stride=2, padding=3))), 3, 2, 1)
+        for li, nblocks in enumerate(LAYERS, start=1):
+            for b in range(nblocks):
+                p = f"layer{li}.{b}"
+                s = 2 if (b == 0 and li > 1) else 1
+                out = F.relu(bn(p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
+                out = F.relu(bn(p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], stride=s, padding=1)))
+                out = bn(p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+                if (p + ".downsample.0.weight") in sd:
+                    x = bn(p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], stride=s))
+                x = F.relu(out + x)
+    return stats

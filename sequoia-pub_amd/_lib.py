@@ -125,6 +125,8 @@ def _declare(lib):
     lib.sq_resnet50_workspace_bytes.argtypes = [i32, i32, i32]
     lib.sq_resnet50_extract.restype = i32
     lib.sq_resnet50_extract.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    lib.sq_resnet50_extract_checked.restype = i32
+    lib.sq_resnet50_extract_checked.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, sz, vp, vp]
     lib.sq_vit_layout_init.restype = i32
     lib.sq_vit_layout_init.argtypes = [ctypes.POINTER(VitConfig), ctypes.POINTER(VitLayout)]
     lib.sq_vit_workspace_bytes.restype = sz

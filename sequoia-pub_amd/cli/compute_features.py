@@ -32,7 +32,9 @@ def main(argv=None):
     parser.add_argument("--tcga_projects", help="the tcga_projects we want to use", default=None, type=str, nargs='*')
     parser.add_argument('--start', type=int, default=0, help='Start slide index for parallelization')
     parser.add_argument('--end', type=int, default=None, help='End slide index for parallelization')
-    parser.add_argument('--compute_dtype', default='fp32', choices=['fp32', 'bf16'])
+    parser.add_argument('--compute_dtype', default='fp32', choices=['fp32', 'bf16', 'f16x3', 'bf16x3'],
+                        help='resnet: f16x3 = split-fp16 planes, fp32-class results at 2.5x the exact fp32 mode (what bench.py quotes); '
+                             'bf16 = throughput mode (not label-exact); uni: fp32 or bf16')
     parser.add_argument('--weights', type=str, default=None,
                         help='resnet: torchvision resnet50 state_dict (.pth), default model_zoo URL; uni: path of pytorch_model.bin (required)')
     args = parser.parse_args(argv)
@@ -43,6 +45,8 @@ def main(argv=None):
         if args.weights:
             model.load_state_dict(torch.load(args.weights, map_location='cpu'))
     elif args.feat_type == 'uni':                                            # compute_features_hdf5.py:62-68
+        if args.compute_dtype not in ('fp32', 'bf16'):
+            raise SystemExit('--feat_type uni runs in fp32 or bf16 (the split modes are the ResNet-50 embedder\'s)')
         from ..uni import create_model
         model = create_model("vit_large_patch16_224", img_size=224, patch_size=16, init_values=1e-5, num_classes=0,
                              dynamic_img_size=True, compute_dtype=args.compute_dtype)

@@ -82,7 +82,7 @@ def embed_tiles(slide, df, patch_size_resized, out_size, feat_model, device, chu
             t = resize_u8(t, out_size)
         feats.append(feat_model.extract_patches_u8(t))
     if not feats:
-        return torch.empty(0, 0, device=device)
+        return torch.empty(0, 2048 if hasattr(feat_model, 'conv1') else 1024, device=device)      # what the extractor would have returned for 0 tiles
     return torch.cat(feats, 0)
 
 
@@ -121,7 +121,8 @@ def main(argv=None):
     p.add_argument('--out_root', type=str, default='./visualizations')
     p.add_argument('--extractor_weights', type=str, default=None, help='resnet50 / UNI state dict (default: torchvision url / ./uni_ckpt/pytorch_model.bin)')
     p.add_argument('--resize_factor', type=float, default=None, help='level-0 pixels per 20x pixel (default: aperio.AppMag / 20)')
-    p.add_argument('--compute_dtype', default='bf16', choices=['fp32', 'bf16'])
+    p.add_argument('--compute_dtype', default='bf16', choices=['fp32', 'bf16', 'f16x3', 'bf16x3'],
+                   help='f16x3 / bf16x3: the ResNet-50 extractor on split planes (fp32-class features); the aggregator then runs in fp32')
     args = p.parse_args(argv)
     assert args.feat_type in ['resnet', 'uni'] and args.model_type in ['vit', 'vis', 'he2rna']
     device = torch.device('cuda:0')
@@ -147,6 +148,10 @@ def main(argv=None):
 
     # ---- feature cache: every valid tile embedded once
     input_dim = 2048 if args.feat_type == 'resnet' else 1024
+    split = args.compute_dtype in ('f16x3', 'bf16x3')          # the ResNet-50 extractor's modes; everything else then runs in fp32
+    if split and args.feat_type != 'resnet':
+        raise SystemExit('--compute_dtype f16x3 / bf16x3 are the ResNet-50 extractor\'s modes; --feat_type uni runs in fp32 or bf16')
+    agg_dtype = 'fp32' if split else args.compute_dtype
     if args.feat_type == 'resnet':
         from ..resnet import resnet50
         feat_model = resnet50(pretrained=args.extractor_weights is None, compute_dtype=args.compute_dtype)
@@ -175,7 +180,7 @@ def main(argv=None):
         fold_ckpt = os.path.join(checkpoint, 'model_best_' + str(fold) + '.pt')
         if fold == 0 and args.model_type in ('vit', 'vis'):
             fold_ckpt = fold_ckpt.replace('_0', '')
-        model = build_model(args.model_type, input_dim, len(gene_ids), device, args.compute_dtype)
+        model = build_model(args.model_type, input_dim, len(gene_ids), device, agg_dtype)
         if args.model_type == 'he2rna':
             obj = torch.load(fold_ckpt.replace('best_', ''), map_location='cpu', weights_only=False)      # he2rna.fit pickles the model
             model.load_state_dict(obj.state_dict() if hasattr(obj, 'state_dict') else obj)

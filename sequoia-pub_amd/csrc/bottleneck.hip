@@ -455,13 +455,13 @@ int sq_launch_bottleneck_tail_c64(const bf16_t* t1, const bf16_t* res, bf16_t* y
     a.P = (int)P; a.W = W; a.HW = H * W; a.tiles = (int)((P + 127) / 128);
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
     a.w2_bytes = clamp(w2_bytes); a.w3_bytes = clamp(w3_bytes); a.w1n_bytes = clamp(w1n_bytes); a.wd_bytes = clamp(wd_bytes);
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_tail_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     int prof = -1;
     if (sq_prof_on()) {

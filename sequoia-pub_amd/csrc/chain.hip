@@ -245,13 +245,13 @@ int sq_launch_bottleneck_chain_c128(const bf16_t* t2, const bf16_t* res, bf16_t*
     a.P = (int)P; a.tiles = (int)((P + tp - 1) / tp);
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
     a.w3_bytes = clamp(w3_bytes); a.w1n_bytes = clamp(w1n_bytes);
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4)));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4)));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(8)));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(8)));
-        attr = true;
+        attr.done();
     }
     int prof = -1;
     if (sq_prof_on()) {

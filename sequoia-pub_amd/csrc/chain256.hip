@@ -238,10 +238,10 @@ int sq_launch_bottleneck_chain_c256(const bf16_t* t2, const bf16_t* res, bf16_t*
     a.P = (int)P; a.tiles = (int)((P + 127) / 128);
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
     a.w3_bytes = clamp(w3_bytes); a.w1n_bytes = clamp(w1n_bytes);
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)btl_chain256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     int prof = -1;
     if (sq_prof_on()) {

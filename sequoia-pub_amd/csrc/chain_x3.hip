@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             const int ck = (brow & 31) >> 3;       // K-tile of the image = channel / 32 (= cj3), 16-byte chunk ck, byte (channel & 7) * 2
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float v0 = fmaxf(s2v * acc3[r] + b2v, 0.f), v1 = fmaxf(s2v * acc3[r + 1] + b2v, 0.f);
+                const float v0 = x3_relu(s2v * acc3[r] + b2v), v1 = x3_relu(s2v * acc3[r + 1] + b2v);
                 const uint32_t h = Fmt::pack2(v0, v1);
                 const uint32_t l = Fmt::pack2(v0 - Fmt::lo_f(h), v1 - Fmt::hi_f(h));
 #pragma unroll
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                     const float d0 = sd * accd[i][j][r] + bd, d1 = sd * accd[i][j][r + 1] + bd;
                     const uint32_t h = Fmt::pack2(d0, d1);
                     const uint32_t l = Fmt::pack2(d0 - Fmt::lo_f(h), d1 - Fmt::hi_f(h));
-                    acc[i][j][r] = fmaxf((s3 * acc[i][j][r] + b3) + (Fmt::lo_f(h) + Fmt::lo_f(l)), 0.f);
-                    acc[i][j][r + 1] = fmaxf((s3 * acc[i][j][r + 1] + b3) + (Fmt::hi_f(h) + Fmt::hi_f(l)), 0.f);
+                    acc[i][j][r] = x3_relu((s3 * acc[i][j][r] + b3) + (Fmt::lo_f(h) + Fmt::lo_f(l)));
+                    acc[i][j][r + 1] = x3_relu((s3 * acc[i][j][r + 1] + b3) + (Fmt::hi_f(h) + Fmt::hi_f(l)));
                 }
         }
     }
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                 float idn[8];
                 x3_join8<F16>(rh[u], rl[u], idn);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf((scale8[e] * v[e] + bias8[e]) + idn[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = x3_relu((scale8[e] * v[e] + bias8[e]) + idn[e]);
             }
             u32x4 hi, lo;
             x3_split8<F16>(v, hi, lo);
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * N2 + e_c8 * 8 + 4);
             float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(s8[e] * v[e] + b8[e], 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = x3_relu(s8[e] * v[e] + b8[e]);
             u32x4 hi, lo;
             x3_split8<F16>(v, hi, lo);
             *reinterpret_cast<u32x4*>(p.t1n + (size_t)m * N2 + e_c8 * 8) = hi;

@@ -230,10 +230,10 @@ int sq_launch_conv1_pool_bf16(const uint8_t* u8, const float* f32_nchw, const bf
     SQ_REQUIRE(tiles < (1ll << 31), "conv1_pool: too many tiles");
     a.tiles = (int)tiles;
     const size_t lds = IN_BYTES + COUT_BYTES + LUT_BYTES;
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv1_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        attr.done();
     }
     const int grid = (int)(tiles < 512 ? tiles : 512);      // persistent: 2 blocks per CU keep their weights in registers
     int prof = -1;

@@ -259,11 +259,11 @@ int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, c
     const long long tiles = (long long)n * a.tiles_per_side * a.tiles_per_side;
     SQ_REQUIRE(tiles < (1ll << 31), "conv1_pool_x3: too many tiles");
     a.tiles = (int)tiles;
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv1_pool_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv1_pool_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     const int grid = (int)(tiles < 256 ? tiles : 256);      // persistent: one block per CU keeps its weight planes in registers
     int prof = -1;

@@ -269,10 +269,10 @@ bool sq_conv_halo_eligible(const GemmArgs& a, int dtype) {
 }
 
 int sq_launch_conv_halo(const GemmArgs& a, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     hipLaunchKernelGGL(conv_halo_kernel, dim3(tiles), dim3(512), LDS_BYTES, stream, a);

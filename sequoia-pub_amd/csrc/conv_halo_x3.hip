@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(const GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             v[e] = scale8[e] * v[e] + bias8[e];
-            if (p.act == SQ_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+            if (p.act == SQ_ACT_RELU) v[e] = x3_relu(v[e]);
         }
         if (c32) {
             float* d = c32 + (long long)m * p.ldc + e_n;
@@ -399,12 +399,13 @@ namespace {
 template <int WTN, int HROWS>
 int launch_halo(const GemmArgs& a, hipStream_t stream) {
     using Cfg = HxCfg<WTN, HROWS>;
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr = true;
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)conv_halo_x3_kernel<WTN, HROWS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr.done();
     }
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / Cfg::BN);
     // all eight waves in step: the A/B switch, and the 64-column tile (12 MFMAs per step and wave: the load phase is the
@@ -413,6 +414,7 @@ int launch_halo(const GemmArgs& a, hipStream_t stream) {
     const bool lockstep = lockstep_env || WTN == 1;
     if (a.x3_f16 && lockstep) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, true, false>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
     else if (a.x3_f16) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, true, true>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
+    else if (lockstep) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, false, false>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
     else hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, false, true>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;

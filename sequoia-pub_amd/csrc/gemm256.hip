@@ -216,11 +216,11 @@ bool sq_gemm256_eligible(const GemmArgs& a, int dtype) {
 namespace {
 template <int EPI>
 int launch256(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
+        attr.done();
     }
     if (a.conv) hipLaunchKernelGGL((gemm_nt256_kernel<EPI, true>), grid, dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((gemm_nt256_kernel<EPI, false>), grid, dim3(512), lds, stream, a);

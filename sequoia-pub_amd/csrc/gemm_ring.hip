@@ -314,11 +314,11 @@ bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype) {
 namespace {
 template <int EPI>
 int launch_ring(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     if (a.conv) hipLaunchKernelGGL((gemm_ring_kernel<EPI, true>), grid, dim3(512), LDS_BYTES, stream, a);
     else hipLaunchKernelGGL((gemm_ring_kernel<EPI, false>), grid, dim3(512), LDS_BYTES, stream, a);

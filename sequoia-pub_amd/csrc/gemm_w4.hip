@@ -331,11 +331,11 @@ int g_w4_waves = -1;              // sq_dbg_set key 9 (tests / probes): 4 or 8 w
 namespace {
 template <int EPI, int NW>
 int launch_w4(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w4_kernel<EPI, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_w4_kernel<EPI, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     if (a.conv) hipLaunchKernelGGL((gemm_w4_kernel<EPI, true, NW>), grid, dim3(64 * NW), LDS_BYTES, stream, a);
     else hipLaunchKernelGGL((gemm_w4_kernel<EPI, false, NW>), grid, dim3(64 * NW), LDS_BYTES, stream, a);

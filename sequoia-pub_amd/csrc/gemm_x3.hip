@@ -450,8 +450,8 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
                         const float d0 = sd * accd[i][j][r] + bd, d1 = sd * accd[i][j][r + 1] + bd;
                         const uint32_t h = Fmt::pack2(d0, d1);
                         const uint32_t l = Fmt::pack2(d0 - Fmt::lo_f(h), d1 - Fmt::hi_f(h));
-                        acc[i][j][r] = fmaxf((s3 * acc[i][j][r] + b3) + (Fmt::lo_f(h) + Fmt::lo_f(l)), 0.f);
-                        acc[i][j][r + 1] = fmaxf((s3 * acc[i][j][r + 1] + b3) + (Fmt::hi_f(h) + Fmt::hi_f(l)), 0.f);
+                        acc[i][j][r] = x3_relu((s3 * acc[i][j][r] + b3) + (Fmt::lo_f(h) + Fmt::lo_f(l)));
+                        acc[i][j][r + 1] = x3_relu((s3 * acc[i][j][r + 1] + b3) + (Fmt::hi_f(h) + Fmt::hi_f(l)));
                     }
             }
         }
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             }
             if (p.act == SQ_ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = x3_relu(v[e]);
             }
             }
             if (p.dbg & 1) continue;
@@ -546,11 +546,11 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
 template <int BM_, int WTN, bool F16, bool PP>
 int launch_x3(const GemmArgs& a, hipStream_t stream) {
     using Cfg = X3Cfg<BM_, WTN>;
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<BM_, WTN, false, F16, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<BM_, WTN, true, F16, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     const int tiles = ((a.M + BM_ - 1) / BM_) * ((a.N + Cfg::BN - 1) / Cfg::BN);
     const dim3 grid(tiles), block(Cfg::NT);
@@ -563,10 +563,10 @@ int launch_x3(const GemmArgs& a, hipStream_t stream) {
 template <bool F16>
 int launch_x3_dual(const GemmArgs& a, hipStream_t stream) {
     using Cfg = X3Cfg<128, 2>;
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_x3_kernel<128, 2, false, F16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     const int tiles = ((a.M + 127) / 128) * (a.N / Cfg::BN);
     hipLaunchKernelGGL((gemm_x3_kernel<128, 2, false, F16, false, true>), dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, a);

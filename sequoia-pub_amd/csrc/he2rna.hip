@@ -114,11 +114,11 @@ extern "C" int sq_he2rna_topk_mean(const float* scores, int ld_scores, const flo
     HeKs k;
     if (int e = fill_ks(ks, n_ks, scale, N, &k)) return e;
     const size_t lds = (size_t)N * HE_THREADS * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)he2rna_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HE_MAX_N * HE_THREADS * 4));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)he2rna_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HE_MAX_N * HE_THREADS * 4));
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL(he2rna_topk_kernel<false>, dim3((G + HE_THREADS - 1) / HE_THREADS, B), dim3(HE_THREADS), lds, (hipStream_t)stream_,
                        scores, ld_scores, mask, k, (const float*)nullptr, out, G, N, G);
@@ -133,10 +133,10 @@ extern "C" int sq_he2rna_topk_mean_bwd(const float* scores, int ld_scores, const
     HeKs k;
     if (int e = fill_ks(ks, n_ks, scale, N, &k)) return e;
     const size_t lds = (size_t)N * HE_THREADS * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)he2rna_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HE_MAX_N * HE_THREADS * 4));
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL(he2rna_topk_kernel<true>, dim3((G + HE_THREADS - 1) / HE_THREADS, B), dim3(HE_THREADS), lds, (hipStream_t)stream_,
                        scores, ld_scores, mask, k, grad_out, grad_scores, ld_grad, N, G);

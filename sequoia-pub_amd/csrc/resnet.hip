@@ -165,8 +165,10 @@ __global__ void avgpool7_kernel(const T* __restrict__ in, float* __restrict__ ou
 // ---- split (SQ_BF16X3 / SQ_F16X3) variants: every tensor is a hi plane and a lo plane of bf16 / fp16 (x3_fmt.h, gemm_x3.hip) ----
 
 // AvgPool2d(7) over hi / lo planes, fp32 out (same summation order as avgpool7_kernel)
+// A non-finite pooled value (an fp16 plane overflowed somewhere upstream: x3_fmt.h x3_relu) ORs 1 into *nonfinite.
 template <bool F16>
-__global__ void avgpool7_x3_kernel(const bf16_t* __restrict__ in, long long plane, float* __restrict__ out, int n, int H, int C) {
+__global__ void avgpool7_x3_kernel(const bf16_t* __restrict__ in, long long plane, float* __restrict__ out, int n, int H, int C,
+                                   unsigned* __restrict__ nonfinite) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * C) return;
     const int c = idx % C, img = idx / C;
@@ -177,6 +179,7 @@ __global__ void avgpool7_x3_kernel(const bf16_t* __restrict__ in, long long plan
             acc += X3Fmt<F16>::one(in[o]) + X3Fmt<F16>::one(in[plane + o]);
         }
     out[idx] = acc / 49.0f;
+    if (nonfinite && !(fabsf(acc) <= 3.0e38f)) atomicOr(nonfinite, 1u);
 }
 
 struct ConvSpec { int cin, cout, k, stride, pad; };
@@ -243,6 +246,13 @@ extern "C" size_t sq_resnet50_workspace_bytes(int dtype, int n_patches, int patc
 extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* bias, const uint8_t* patches_u8,
                                    const float* patches_f32_nchw, int n, int S, float* features, void* workspace,
                                    size_t workspace_bytes, sq_stream_t stream_) {
+    return sq_resnet50_extract_checked(dtype, weights, bias, patches_u8, patches_f32_nchw, n, S, features, workspace, workspace_bytes,
+                                       nullptr, stream_);
+}
+
+extern "C" int sq_resnet50_extract_checked(int dtype, const void* weights, const float* bias, const uint8_t* patches_u8,
+                                           const float* patches_f32_nchw, int n, int S, float* features, void* workspace,
+                                           size_t workspace_bytes, uint32_t* nonfinite_flag, sq_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16 || dtype == SQ_BF16X3 || dtype == SQ_F16X3, "resnet50: dtype %d", dtype);
     SQ_REQUIRE(weights && bias && features && workspace, "resnet50: null pointer");
@@ -447,8 +457,8 @@ extern "C" int sq_resnet50_extract(int dtype, const void* weights, const float* 
         }
     {
         const int total = n * 2048;
-        if (f16) hipLaunchKernelGGL(avgpool7_x3_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], act_plane, features, n, H, 2048);
-        else if (x3) hipLaunchKernelGGL(avgpool7_x3_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], act_plane, features, n, H, 2048);
+        if (f16) hipLaunchKernelGGL(avgpool7_x3_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], act_plane, features, n, H, 2048, nonfinite_flag);
+        else if (x3) hipLaunchKernelGGL(avgpool7_x3_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], act_plane, features, n, H, 2048, nonfinite_flag);
         else if (lp) hipLaunchKernelGGL(avgpool7_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)b.act[xi], features, n, H, 2048);
         else hipLaunchKernelGGL(avgpool7_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)b.act[xi], features, n, H, 2048);
         SQ_LAUNCH_CHECK();

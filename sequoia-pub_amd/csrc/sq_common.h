@@ -26,6 +26,15 @@ bool sq_env_flag(const char* name);                           // set and not "0"
 int sq_prof_begin(const char* name, double flops, double bytes, hipStream_t st);
 void sq_prof_end(int idx, hipStream_t st);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a launcher's attribute block has to run once for
+// every device the process drives, not once per process.  Setting it twice from two threads is harmless.
+struct SqDevOnce {
+    unsigned long long mask = 0;
+    static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    bool needed() const { return (__atomic_load_n(&mask, __ATOMIC_ACQUIRE) & bit()) == 0; }
+    void done() { __atomic_fetch_or(&mask, bit(), __ATOMIC_RELEASE); }
+};
+
 #define SQ_HIP_CHECK(expr)                                                        \
     do {                                                                          \
         hipError_t _e = (expr);                                                   \

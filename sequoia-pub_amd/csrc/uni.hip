@@ -404,12 +404,12 @@ extern "C" int sq_uni_forward(const sq_uni_config* c, int dtype, const float* pa
     const size_t att_lds = ((size_t)T * DH * 2 + (size_t)T * (DH + 1) + 4 * ATT_MAXT) * sizeof(float);
     const size_t att_mfma_lds = 256 * 128 + 64 * VT_LD * 2 + 4 * 4096;
     const bool valu_attn = sq_env_flag("SQ_UNI_VALU_ATTN") || (T + 31) / 32 * 32 > VT_LD - 8;   // A/B knob; V^T rows hold <= 224 keys
-    static bool attr = false;
-    if (!attr) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)uni_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_mfma_lds));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)uni_attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)uni_attn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        attr.done();
     }
     float* X = w.X;
     float* X1 = w.X1;

@@ -39,6 +39,11 @@ template <> struct X3Fmt<true> {
     }
 };
 
+// ReLU of the split modes: lets NaN through.  An activation beyond fp16's range splits into hi = +inf, lo = -inf, the next
+// product turns that into NaN -- and fmaxf(NaN, 0) = 0 would hide it in the very next epilogue.  With this form the NaN
+// reaches the pooled features, where avgpool7_x3_kernel raises the caller's non-finite flag (resnet.hip).
+__device__ __forceinline__ float x3_relu(float v) { return v < 0.f ? 0.f : v; }
+
 // 8 fp32 values -> packed hi / lo planes (16 bytes each)
 template <bool F16>
 __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {

@@ -31,6 +31,55 @@ class SlidePipeline:
         r = kmeans_fit_batch(features, self.n_clusters, random_state=0)
         return r["cluster_features"], r["labels"]
 
+    # ---- one slide: embed on the main stream, cluster on the side stream ------------------------------------------
+    def _side_stream(self, dev):
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
+    def _embed_deferred(self, p, main):
+        """Enqueue the embedding of one slide on the main stream without any host sync.  Split-fp16 embedder: the launch
+        groups OR their non-finite flag (resnet.extract_patches_u8 'defer') into a per-slide device word whose copy to
+        pinned host memory is enqueued behind them; _cluster_on_side reads it where the host waits for k-Means anyway."""
+        if isinstance(p, tuple):                   # (tensor, event): an upload still in flight on a copy stream
+            p, uploaded = p
+            main.wait_event(uploaded)
+        host_flag = None
+        if getattr(self.resnet, "compute_dtype", None) == _lib.SQ_F16X3:
+            flag = self.resnet.new_flag()
+            f = self.resnet.extract_patches_u8(p, sub_batch=self.sub_batch, on_nonfinite="defer", flag=flag)
+            host_flag = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host_flag.copy_(flag, non_blocking=True)
+        else:
+            f = self.embed(p)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        return f, ev, p, host_flag
+
+    def _cluster_on_side(self, item, main, side):
+        """k-Means + cluster means of one embedded slide on the side stream (the host polls convergence there while the
+        main stream already holds the next slide's embedding).  Returns (features, cluster_features, labels, event)."""
+        f, ev, p, host_flag = item
+        side.wait_event(ev)
+        f.record_stream(side)
+        with torch.cuda.stream(side):
+            cf, lab = self.cluster(f.unsqueeze(0))
+            if host_flag is not None:
+                ev.synchronize()                   # long complete: the k-Means above polled the host behind it
+                if int(host_flag[0]) != 0:         # an fp16 plane overflowed in this slide: embed it again in exact fp32
+                    import warnings
+                    warnings.warn("split-fp16 embedder: an activation left fp16's range in one slide; the slide is re-embedded in exact fp32",
+                                  RuntimeWarning, stacklevel=2)
+                    self.nonfinite_reruns = getattr(self, "nonfinite_reruns", 0) + 1
+                    f = self.resnet.exact_twin().extract_patches_u8(p.to(f.device), 128)
+                    cf, lab = self.cluster(f.unsqueeze(0))
+                    f.record_stream(main)
+            fin = torch.cuda.Event()
+            fin.record(side)
+        cf.record_stream(main)
+        lab.record_stream(main)
+        return f, cf, lab[0], fin
+
     @torch.no_grad()
     def __call__(self, slides_u8):
         """slides_u8: list of [n_i, S, S, 3] uint8 tensors (or (tensor, torch.cuda.Event) pairs whose upload is
@@ -42,42 +91,22 @@ class SlidePipeline:
         stream -- keeps the chip busy, so only the last slide's clustering is exposed."""
         dev = self.vis.flat.device
         main = torch.cuda.current_stream(dev)
-        if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
-        side = self._side
-        feats, cfs, labels = [], [], []
+        side = self._side_stream(dev)
         if len(slides_u8) == 0:
             z = torch.empty(0, self.vis.cfg.num_outputs, device=dev)
             return dict(pred=z, cluster_features=torch.empty(0, self.n_clusters, self.vis._dim(), device=dev), labels=[], features=[])
-
-        def cluster_on_side(f, ev):
-            side.wait_event(ev)
-            f.record_stream(side)
-            with torch.cuda.stream(side):
-                cf, lab = self.cluster(f.unsqueeze(0))
-            cf.record_stream(main)
-            lab.record_stream(main)
-            cfs.append(cf)
-            labels.append(lab[0])
-
+        done = []
         pending = None
         for p in slides_u8:
-            if isinstance(p, tuple):               # (tensor, event): an upload still in flight on a copy stream
-                p, uploaded = p
-                main.wait_event(uploaded)
-            f = self.embed(p)                      # enqueued first: the GPU has this to chew on ...
-            ev = torch.cuda.Event()
-            ev.record(main)
-            feats.append(f)
+            item = self._embed_deferred(p, main)   # enqueued first: the GPU has this to chew on ...
             if pending is not None:
-                cluster_on_side(*pending)          # ... while the host drives the previous slide's k-Means
-            pending = (f, ev)
-        if pending is not None:
-            cluster_on_side(*pending)
+                done.append(self._cluster_on_side(pending, main, side))      # ... while the host drives the previous slide's k-Means
+            pending = item
+        done.append(self._cluster_on_side(pending, main, side))
         main.wait_stream(side)
-        cf = torch.cat(cfs)
+        cf = torch.cat([d[1] for d in done])
         pred = self.vis(cf)
-        return dict(pred=pred, cluster_features=cf, labels=labels, features=feats)
+        return dict(pred=pred, cluster_features=cf, labels=[d[2] for d in done], features=[d[0] for d in done])
 
     # ---- streaming form: throughput over latency -------------------------------------------------------------
     @torch.no_grad()
@@ -88,32 +117,13 @@ class SlidePipeline:
         for the slides finished so far, possibly of the previous group), or None.  Call flush() after the last group."""
         dev = self.vis.flat.device
         main = torch.cuda.current_stream(dev)
-        if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
-        side = self._side
+        side = self._side_stream(dev)
         st = self.__dict__.setdefault("_stream_state", dict(pending=None, done=[]))
-
-        def cluster_on_side(f, ev):
-            side.wait_event(ev)
-            f.record_stream(side)
-            with torch.cuda.stream(side):
-                cf, lab = self.cluster(f.unsqueeze(0))
-                fin = torch.cuda.Event()
-                fin.record(side)
-            cf.record_stream(main)
-            lab.record_stream(main)
-            st["done"].append((f, cf, lab[0], fin))
-
         for p in slides_u8:
-            if isinstance(p, tuple):
-                p, uploaded = p
-                main.wait_event(uploaded)
-            f = self.embed(p)
-            ev = torch.cuda.Event()
-            ev.record(main)
+            item = self._embed_deferred(p, main)
             if st["pending"] is not None:
-                cluster_on_side(*st["pending"])
-            st["pending"] = (f, ev)
+                st["done"].append(self._cluster_on_side(st["pending"], main, side))
+            st["pending"] = item
         return self._collect(main)
 
     def _collect(self, main):
@@ -135,16 +145,6 @@ class SlidePipeline:
         dev = self.vis.flat.device
         main = torch.cuda.current_stream(dev)
         if st["pending"] is not None:
-            f, ev = st["pending"]
-            st["pending"] = None
-            side = self._side
-            side.wait_event(ev)
-            f.record_stream(side)
-            with torch.cuda.stream(side):
-                cf, lab = self.cluster(f.unsqueeze(0))
-                fin = torch.cuda.Event()
-                fin.record(side)
-            cf.record_stream(main)
-            lab.record_stream(main)
-            st["done"].append((f, cf, lab[0], fin))
+            item, st["pending"] = st["pending"], None
+            st["done"].append(self._cluster_on_side(item, main, self._side_stream(dev)))
         return self._collect(main)

@@ -150,7 +150,36 @@ class ResNet50(nn.Module):
             raise NotImplementedError("sequoia-pub_amd ResNet50 runs in eval mode only (as the reference does)")
         return super().train(mode)
 
-    def _run(self, patches_u8=None, x_f32=None, slot=0):
+    # ---- the reduced range of the split-fp16 mode ----------------------------------------------------------------
+    def exact_twin(self):
+        """The same network in the exact fp32 mode (shares the parameters): what a launch group is re-run in when the
+        split-fp16 mode overflowed (an activation >= 65504; sq_resnet50_extract_checked)."""
+        tw = self.__dict__.get("_twin")
+        if tw is None:
+            tw = ResNet50(compute_dtype="fp32")
+            tw._built = True
+            self.__dict__["_twin"] = tw                  # not a registered submodule: state_dict() keeps the reference's keys
+        tw.load_state_dict(self.state_dict())
+        return tw.to(self.conv1.weight.device).eval()
+
+    def new_flag(self):
+        """A zeroed device word for sq_resnet50_extract_checked's non-finite flag."""
+        return torch.zeros(1, dtype=torch.int32, device=self.conv1.weight.device)
+
+    def _resolve_nonfinite(self, feats, flag, on_nonfinite, rerun):
+        """Read the flag (host sync); overflowed -> raise, or re-run in fp32 (`rerun()` returns the exact features)."""
+        if flag is None or int(flag.item()) == 0:
+            return feats
+        msg = ("ResNet50 in split-fp16 mode (f16x3): an activation left fp16's range (>= 65504) and the features are not finite"
+               " -- unusual weights or BatchNorm statistics")
+        if on_nonfinite == "raise":
+            raise _lib.SequoiaHipError(msg + "; use compute_dtype='fp32' or 'bf16x3' for this checkpoint")
+        import warnings
+        warnings.warn(msg + "; this launch group is re-run in exact fp32", RuntimeWarning, stacklevel=3)
+        self.last_nonfinite_reruns = getattr(self, "last_nonfinite_reruns", 0) + 1
+        return rerun()
+
+    def _run(self, patches_u8=None, x_f32=None, slot=0, flag=None):
         _lib.require_gpu()
         w, b = self._pack()
         if not w.is_cuda:
@@ -168,29 +197,53 @@ class ResNet50(nn.Module):
         if ws is None or ws.numel() < need or ws.device != w.device:
             ws = self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(_lib.lib().sq_resnet50_extract(self.compute_dtype, _lib.ptr(w), _lib.ptr(b), _lib.ptr(patches_u8),
-                                                      _lib.ptr(x_f32), n, S, _lib.ptr(feats), _lib.ptr(ws),
-                                                      ws.numel(), _lib.stream_ptr(w.device)))
+            _lib.check(_lib.lib().sq_resnet50_extract_checked(self.compute_dtype, _lib.ptr(w), _lib.ptr(b), _lib.ptr(patches_u8),
+                                                              _lib.ptr(x_f32), n, S, _lib.ptr(feats), _lib.ptr(ws), ws.numel(),
+                                                              _lib.ptr(flag) if flag is not None else None,
+                                                              _lib.stream_ptr(w.device)))
         return feats
 
     @torch.no_grad()
-    def forward_extract(self, x):
+    def forward_extract(self, x, on_nonfinite="rerun"):
         """src/resnet.py:155-170: x f32 [n, 3, H, W] (normalised) -> f32 [n, 2048]."""
         dev = self.conv1.weight.device
-        return self._run(x_f32=x.to(dev, torch.float32).contiguous())
+        x = x.to(dev, torch.float32).contiguous()
+        flag = self.new_flag() if self.compute_dtype == _lib.SQ_F16X3 else None
+        feats = self._run(x_f32=x, flag=flag)
+        return self._resolve_nonfinite(feats, flag, on_nonfinite,
+                                       lambda: torch.cat([self.exact_twin()._run(x_f32=x[i:i + 128]) for i in range(0, x.shape[0], 128)]))
 
     @torch.no_grad()
-    def extract_patches_u8(self, patches, sub_batch=500):
+    def max_sub_batch(self, S):
+        """Largest launch group the 2 GiB buffer-descriptor limit allows at patch size S (sq_resnet50_extract's check): the
+        [n, S/2, S/2, 64] activation planes, and in fp32 mode the [n (S/2)^2, 152] im2col matrix of the stem."""
+        es = 4 if self.compute_dtype == _lib.SQ_F32 else 2
+        per = (S // 2) ** 2 * (152 if self.compute_dtype == _lib.SQ_F32 else 64) * es
+        return max(1, ((1 << 31) - 1) // per)
+
+    def extract_patches_u8(self, patches, sub_batch=500, on_nonfinite="rerun", flag=None):
         """uint8 HWC patches [n, S, S, 3] -> f32 [n, 2048]; fuses compute_features_hdf5.py:119-120's transform.
-        Patches go through in sub-batches of <= 500 (the 2 GiB buffer-descriptor limit of the conv1 im2col
-        matrix); larger sub-batches measured faster (38.1 slides/s at 500 vs 34.9 at 200) -- longer grids, fewer tails."""
+        Patches go through in launch groups of <= sub_batch (clamped to what the 2 GiB buffer-descriptor limit allows for
+        this mode and patch size); larger groups measured faster -- longer grids, fewer tails.
+        Split-fp16 mode: a group whose features came out non-finite (an activation beyond fp16's range) is, per
+        `on_nonfinite`, re-run in exact fp32 with a warning ("rerun", one host sync per call), reported by an exception
+        ("raise"), or left to the caller ("defer": no sync; pass `flag`, a zeroed int32 device word from new_flag(), and
+        check it later -- SlidePipeline does)."""
         dev = self.conv1.weight.device
         patches = torch.as_tensor(patches)
         if patches.shape[0] == 0:                        # a slide whose patch store is empty: no features, no launch
             return torch.empty(0, 2048, dtype=torch.float32, device=dev)
+        sub_batch = max(1, min(int(sub_batch), self.max_sub_batch(patches.shape[1])))
+        if self.compute_dtype == _lib.SQ_F16X3:
+            if on_nonfinite != "defer":
+                flag = self.new_flag()
+                feats = self.extract_patches_u8(patches, sub_batch, "defer", flag)
+                return self._resolve_nonfinite(feats, flag, on_nonfinite, lambda: self.exact_twin().extract_patches_u8(patches, 128))
+        else:
+            flag = None
         chunks = [patches[i:i + sub_batch] for i in range(0, patches.shape[0], sub_batch)]
         if len(chunks) == 1 or not patches.is_cuda:
-            return torch.cat([self._run(patches_u8=c.to(dev).contiguous()) for c in chunks], 0)
+            return torch.cat([self._run(patches_u8=c.to(dev).contiguous(), flag=flag) for c in chunks], 0)
         # Two sub-batches in flight on two streams (own workspaces): every convolution of the chain is one launch
         # that depends on the previous one, so a single chain leaves the chip idle in each launch's ramp-up, tail and
         # store-drain phase; a second, independent chain fills those.
@@ -206,7 +259,7 @@ class ResNet50(nn.Module):
             st = self._streams[i % ns]
             st.wait_event(start)
             with torch.cuda.stream(st):
-                outs[i] = self._run(patches_u8=c.contiguous(), slot=i % ns)
+                outs[i] = self._run(patches_u8=c.contiguous(), slot=i % ns, flag=flag)
         for st in self._streams:
             main.wait_stream(st)
         for o in outs:

@@ -429,6 +429,61 @@ def gold_pipeline():
     print("pipeline: n_iter", km.n_iter_, "pred mean |.|", float(np.abs(pred).mean()), "clusters min size", int(np.bincount(labels).min()))
 
 
+
+def _reference_slide(sd_r, patches, out_name, extra=None, probe_step=16):
+    """One slide through the reference's pieces (see gold_pipeline) -> tests/golden/<out_name>.npz."""
+    from sklearn.cluster import KMeans
+    rn = resnet50(pretrained=False)
+    full = rn.state_dict()
+    full.update(sd_r)
+    rn.load_state_dict(full)
+    rn.eval()
+    feats = []
+    with torch.no_grad():
+        for i in range(0, len(patches), 50):
+            feats.append(rn.forward_extract(resnet_oracle.transform_patch_u8(patches[i:i + 50])))
+    feats = torch.cat(feats).numpy()
+    assert np.isfinite(feats).all()
+    km = KMeans(n_clusters=100, random_state=0).fit(feats)
+    labels = km.labels_.astype(np.int16)
+    cf = np.stack([feats[labels == j].mean(axis=0) for j in range(100)]).astype(np.float32)
+    cfg = dict(num_outputs=20820, input_dim=2048, depth=6, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd_v = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=31), seed=32)
+    model = ViS(**cfg, num_clusters=100, device="cpu")
+    model.load_state_dict(sd_v)
+    with torch.no_grad():
+        pred = model(torch.from_numpy(cf)[None])[0].numpy()
+    np.savez_compressed(os.path.join(HERE, out_name + ".npz"), labels=labels, n_iter=np.array(km.n_iter_),
+                        feat_rowsum=feats.sum(1).astype(np.float64), feat_probe=feats[::probe_step].copy(), probe_step=np.array(probe_step),
+                        cluster_features_rowsum=cf.sum(1).astype(np.float64), pred=pred,
+                        resnet_checksum=checksum(sd_r), vis_checksum=checksum(sd_v),
+                        sklearn_version=np.array(__import__("sklearn").__version__), **(extra or {}))
+    print(out_name, ": n_iter", km.n_iter_, "feature max", float(feats.max()), "zero share", float((feats == 0).mean()),
+          "pred mean |.|", float(np.abs(pred).mean()), "clusters min/max size", int(np.bincount(labels).min()), int(np.bincount(labels).max()))
+
+
+def gold_pipeline_hard():
+    """Three more full-size slides through the reference (src/resnet.py forward_extract, scikit-learn KMeans, src/tformer_lin.py
+    ViS; compute_features_hdf5.py:116-123, kmean_features.py:96-105), harder on a reduced-range arithmetic than the
+    uniform-noise slide of gold_pipeline: STRUCTURED patches (synth.structured_patches_u8: white background, saturated and
+    near-black regions, almost flat tiles, smooth gradients) at 224 and at 256 px -- the reference's default patch size,
+    patch_gen_hdf5.py:157 -- and a WIDE-RANGE weight set (resnet_oracle.init_resnet50_state_dict_wide: weight rows over two
+    decades, BN gamma 0.1 .. 10, running statistics calibrated on a batch and stored as resnet50_wide_bn.npz: running_var
+    over > 4 decades, folded scale gamma / sqrt(var) over > 4 decades)."""
+    sd_std = resnet_oracle.init_resnet50_state_dict(seed=99, perturb_bn=True)
+    _reference_slide(sd_std, synth.structured_patches_u8(11, 1000, 224), "pipeline_slide_struct224")
+    _reference_slide(sd_std, synth.structured_patches_u8(12, 1000, 256), "pipeline_slide_struct256")
+    sd_w = resnet_oracle.init_resnet50_state_dict_wide(123)
+    calib = np.concatenate([synth.structured_patches_u8(50, 20, 224), synth.patches_u8(50, 12, 224)])
+    stats = resnet_oracle.calibrate_bn(sd_w, resnet_oracle.transform_patch_u8(calib))
+    np.savez_compressed(os.path.join(HERE, "resnet50_wide_bn.npz"), **stats)
+    sd_w = resnet_oracle.init_resnet50_state_dict_wide(123, running_stats=np.load(os.path.join(HERE, "resnet50_wide_bn.npz")))
+    var = np.concatenate([v for k, v in stats.items() if k.endswith("running_var")])
+    scale = np.concatenate([(sd_w[k[:-len("running_var")] + "weight"] / torch.sqrt(sd_w[k] + 1e-5)).numpy() for k in sd_w if k.endswith("running_var")])
+    _reference_slide(sd_w, synth.structured_patches_u8(13, 1000, 224), "pipeline_slide_wide224",
+                     extra=dict(running_var_range=np.array([var.min(), var.max()]), folded_scale_range=np.array([scale.min(), scale.max()])))
+
+
 def gold_he2rna():
     """src/he2rna.py:42-106 (HE2RNA, the benchmark comparator of pretrain_gtex.py:102-105): seeded weights and inputs,
     eval-mode forward (mean over ks), forward_fixed_k for three k, and the autograd gradients of one fixed-k forward
@@ -462,7 +517,7 @@ def gold_he2rna():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats", "early_stop", "kfold", "pipeline", "he2rna"]
+    which = sys.argv[1:] or ["vis_tiny", "vit_tiny", "vis_full", "resnet", "kmeans", "metrics", "evalstats", "early_stop", "kfold", "pipeline", "he2rna", "pipeline_hard"]
     if "vit_tiny" in which:
         gold_vit_tiny()
     if "vis_tiny" in which:
@@ -485,3 +540,5 @@ if __name__ == "__main__":
         gold_pipeline()
     if "he2rna" in which:
         gold_he2rna()
+    if "pipeline_hard" in which:
+        gold_pipeline_hard()

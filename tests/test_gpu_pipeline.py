@@ -26,9 +26,26 @@ def _checksum(sd):
     return np.array([s, a])
 
 
-def _models(mode):
+# The reference-made slides (make_golden.py gold_pipeline / gold_pipeline_hard): fixture, patch recipe, patch size, weight set
+SLIDES = {
+    "noise224": ("pipeline_slide.npz", lambda: synth.patches_u8(7, 1000, 224), "std"),
+    "struct224": ("pipeline_slide_struct224.npz", lambda: synth.structured_patches_u8(11, 1000, 224), "std"),
+    "struct256": ("pipeline_slide_struct256.npz", lambda: synth.structured_patches_u8(12, 1000, 256), "std"),
+    "wide224": ("pipeline_slide_wide224.npz", lambda: synth.structured_patches_u8(13, 1000, 224), "wide"),
+}
+
+
+def _resnet_weights(kind, golden_dir=None):
+    if kind == "std":
+        return ro.init_resnet50_state_dict(seed=99, perturb_bn=True)
+    import conftest
+    stats = np.load(os.path.join(golden_dir or conftest.GOLDEN, "resnet50_wide_bn.npz"))
+    return ro.init_resnet50_state_dict_wide(123, running_stats=stats)
+
+
+def _models(mode, weights="std"):
     vis_mode = "fp32" if mode in ("bf16x3", "f16x3") else mode      # split-bf16 is the embedder's mode; the aggregator (0.2 % of the FLOP) stays exact fp32
-    sd_r = ro.init_resnet50_state_dict(seed=99, perturb_bn=True)
+    sd_r = _resnet_weights(weights)
     rn = resnet50(pretrained=False, compute_dtype=mode)
     full = rn.state_dict()
     full.update(sd_r)
@@ -79,20 +96,26 @@ def _partition_agreement(a, b):
     return float((total + 2 * same_both - same_a - same_b) / total)
 
 
-def accuracy_vs_golden(mode, golden_dir, sub_batch=250):
-    """One 1000-patch slide (the slide of pipeline_slide.npz) through SlidePipeline in `mode`; the figures bench.py
-    prints as ``accuracy_vs_reference``."""
-    z = np.load(os.path.join(golden_dir, "pipeline_slide.npz"))
-    rn, vis, sd_r, sd_v = _models(mode)
+def accuracy_vs_golden(mode, golden_dir, sub_batch=250, slide="noise224"):
+    """One reference-made 1000-patch slide (SLIDES) through SlidePipeline in `mode`; the figures bench.py prints as
+    ``accuracy_vs_reference``."""
+    fixture, make_patches, weights = SLIDES[slide]
+    z = np.load(os.path.join(golden_dir, fixture))
+    rn, vis, sd_r, sd_v = _models(mode, weights)
+    assert np.allclose(_checksum(sd_r), z["resnet_checksum"], rtol=1e-9) and np.allclose(_checksum(sd_v), z["vis_checksum"], rtol=1e-9), \
+        "the weight recipe drifted from the one the golden was made with"
     pipe = SlidePipeline(rn, vis, n_clusters=100, sub_batch=sub_batch)
-    patches = torch.from_numpy(synth.patches_u8(7, 1000, 224)).cuda()
+    patches = torch.from_numpy(make_patches()).cuda()
     out = pipe([patches])
     torch.cuda.synchronize()
     feats = out["features"][0].cpu().numpy()
     labels = out["labels"][0].cpu().numpy()
     pred = out["pred"][0].cpu().numpy()
     cf_sum = out["cluster_features"][0].double().sum(1).cpu().numpy()
-    return dict(feature_rel_err=rel_err(feats[::64], z["feat_probe"]),
+    step = int(z["probe_step"]) if "probe_step" in z else 64
+    return dict(feature_rel_err=rel_err(feats[::step], z["feat_probe"]),
+                feature_allclose_1e4_fraction=close_fraction(feats[::step], z["feat_probe"], 1e-4),
+                reruns_in_fp32=int(getattr(pipe, "nonfinite_reruns", 0)),
                 feature_rowsum_rel_err=rel_err(feats.astype(np.float64).sum(1), z["feat_rowsum"]),
                 labels_equal_fraction=float((labels == z["labels"]).mean()),
                 partition_rand_index=_partition_agreement(labels, z["labels"]),
@@ -112,6 +135,77 @@ def test_full_size_slide_split_fp16_matches_reference_golden(golden_dir):
     assert np.array_equal(labels, z["labels"])                    # bit-exact cluster assignments (north_star)
     assert acc["prediction_rel_err"] < 1e-4
     assert_allclose_rel(pred, z["pred"], 1e-4, "20 820-gene prediction of the slide, split-fp16 embedder")
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "fp32"])
+@pytest.mark.parametrize("slide", ["struct224", "struct256", "wide224"])
+def test_hard_slides_match_reference_golden(golden_dir, slide, mode):
+    """The headline's numeric mode (split fp16) and the exact fp32 mode on the three reference-made slides that are hard on a
+    reduced-range arithmetic (make_golden.py gold_pipeline_hard): structured patches -- white background, saturated and
+    near-black regions, almost flat tiles -- at 224 and at the reference's default 256 px (patch_gen_hdf5.py:157), and a
+    weight set whose BN statistics span > 4 decades.  Same bar as the uniform-noise slide: features within 1e-4 in the
+    max-norm AND per element (allclose form), the 1000 k-Means labels bit-equal to scikit-learn's on the reference's
+    features (8-13 Lloyd iterations, clusters of a single patch), the 20 820-gene prediction within 1e-4; no fp32 re-run."""
+    _lib.require_gpu()
+    acc, labels, pred, z = accuracy_vs_golden(mode, golden_dir, sub_batch=500, slide=slide)
+    print(f"config 3, {slide}, {mode} vs the reference golden: " + ", ".join(f"{k} {v:.3e}" for k, v in acc.items()))
+    assert acc["reruns_in_fp32"] == 0
+    assert acc["feature_rel_err"] < 1e-4 and acc["feature_rowsum_rel_err"] < 1e-4
+    assert acc["feature_allclose_1e4_fraction"] == 1.0
+    assert np.array_equal(labels, z["labels"])                    # bit-exact cluster assignments (north_star)
+    assert acc["prediction_rel_err"] < 1e-4
+    assert_allclose_rel(pred, z["pred"], 1e-4, f"20 820-gene prediction of the {slide} slide, {mode} embedder")
+
+
+def test_split_fp16_overflow_is_detected_and_rerun_in_fp32(golden_dir):
+    """fp16 planes end at 65504.  A checkpoint whose activations go beyond it (here: one BatchNorm gain times 3e4 in layer 1,
+    so the NaN has to survive 45 more convolutions -- the split modes' ReLU lets it through -- and another in layer 4) must
+    not produce silently wrong features: the checked entry point raises its flag, 'raise' raises, the default re-runs the
+    launch group in exact fp32 and returns exactly what the fp32 mode returns; SlidePipeline does the same per slide without
+    a host sync on the fast path."""
+    import warnings
+    _lib.require_gpu()
+    patches = torch.from_numpy(synth.structured_patches_u8(21, 40, 224)).cuda()
+    for where in ("layer1.0.bn3", "layer4.1.bn2"):
+        sd = ro.init_resnet50_state_dict(seed=99, perturb_bn=True)
+        sd[where + ".weight"] = sd[where + ".weight"] * 3.0e4
+        nets = {}
+        for mode in ("f16x3", "fp32"):
+            m = resnet50(pretrained=False, compute_dtype=mode)
+            full = m.state_dict()
+            full.update(sd)
+            m.load_state_dict(full)
+            nets[mode] = m.to("cuda:0").eval()
+        exact = nets["fp32"].extract_patches_u8(patches, sub_batch=128)
+        assert torch.isfinite(exact).all() and float(exact.max()) > 1e3
+        flag = nets["f16x3"].new_flag()
+        raw = nets["f16x3"].extract_patches_u8(patches, on_nonfinite="defer", flag=flag)
+        assert int(flag.item()) == 1 and not torch.isfinite(raw).all(), where
+        with pytest.raises(_lib.SequoiaHipError, match="65504"):
+            nets["f16x3"].extract_patches_u8(patches, on_nonfinite="raise")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = nets["f16x3"].extract_patches_u8(patches)
+        assert any("fp16" in str(x.message) for x in w)
+        assert torch.equal(got, exact), where
+    # the pipeline: both slides overflow -> each is re-embedded in fp32 on the side stream, results equal the fp32 pipeline's
+    cfg = dict(VIS2048, num_outputs=300, depth=1)
+    torch.manual_seed(5)
+    vis = ViS(**cfg, device="cuda:0", compute_dtype="fp32").to("cuda:0").eval()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        pipe = SlidePipeline(nets["f16x3"], vis, n_clusters=8, sub_batch=500)
+        out = pipe([patches, patches[:24]])
+        torch.cuda.synchronize()
+    ref = SlidePipeline(nets["fp32"], vis, n_clusters=8, sub_batch=128)([patches, patches[:24]])
+    torch.cuda.synchronize()
+    assert pipe.nonfinite_reruns == 2
+    assert all(torch.equal(a, b) for a, b in zip(out["labels"], ref["labels"])) and torch.equal(out["pred"], ref["pred"])
+    # and a healthy network never takes that path
+    rn, _, _, _ = _models("f16x3")
+    flag = rn.new_flag()
+    ok = rn.extract_patches_u8(patches, on_nonfinite="defer", flag=flag)
+    assert int(flag.item()) == 0 and torch.isfinite(ok).all()
 
 
 def test_full_size_slide_split_bf16_matches_reference_golden(golden_dir):

@@ -29,6 +29,30 @@ def test_resnet50_forward_extract_matches_reference(golden_dir):
     np.testing.assert_allclose(inter["layer2"][0, ::32, ::4, ::4].numpy(), z["ref_layer2_sample"], rtol=1e-4, atol=1e-4)
 
 
+def test_oracle_on_the_hard_slides_matches_reference(golden_dir):
+    """The structured-patch slides (224 / 256 px) and the wide-range weight set of make_golden.py gold_pipeline_hard: the
+    oracle's features of probe patches 0, 16, 32 against the reference's (every 16th row is stored).  (The
+    labels need all 1000 feature rows: they are checked on the GPU box, tests/test_gpu_pipeline.py.)"""
+    torch.set_num_threads(8)
+    for fixture, slide_idx, size, wide in (("pipeline_slide_struct224.npz", 11, 224, False), ("pipeline_slide_struct256.npz", 12, 256, False),
+                                           ("pipeline_slide_wide224.npz", 13, 224, True)):
+        z = np.load(os.path.join(golden_dir, fixture))
+        step = int(z["probe_step"])
+        if wide:
+            sd = ro.init_resnet50_state_dict_wide(123, running_stats=np.load(os.path.join(golden_dir, "resnet50_wide_bn.npz")))
+            assert z["running_var_range"][1] / z["running_var_range"][0] > 1e4 and z["folded_scale_range"][1] / z["folded_scale_range"][0] > 1e4
+        else:
+            sd = ro.init_resnet50_state_dict(seed=99, perturb_bn=True)
+        s = sum(float(v.double().sum()) for v in sd.values())
+        a = sum(float(v.double().abs().sum()) for v in sd.values())
+        np.testing.assert_allclose([s, a], z["resnet_checksum"], rtol=1e-9)
+        patches = synth.structured_patches_u8(slide_idx, 2 * step + 1, size)        # the generator's stream is per patch: a prefix is enough
+        f = ro.embed_patches(sd, patches[::step], batch=1).numpy()
+        ref = z["feat_probe"][:3]
+        assert np.abs(f - ref).max() <= 1e-5 * np.abs(ref).max(), fixture
+        np.testing.assert_allclose(f.astype(np.float64).sum(1), z["feat_rowsum"][:2 * step + 1:step], rtol=1e-5)
+
+
 def test_metrics_match_reference(golden_dir):
     z = np.load(os.path.join(golden_dir, "metrics_train.npz"))
     labels, preds = z["labels"], z["preds"]
