@@ -191,7 +191,7 @@ def test_split_fp16_overflow_is_detected_and_rerun_in_fp32(golden_dir):
     # the pipeline: both slides overflow -> each is re-embedded in fp32 on the side stream, results equal the fp32 pipeline's
     cfg = dict(VIS2048, num_outputs=300, depth=1)
     torch.manual_seed(5)
-    vis = ViS(**cfg, device="cuda:0", compute_dtype="fp32").to("cuda:0").eval()
+    vis = ViS(**cfg, num_clusters=8, device="cuda:0", compute_dtype="fp32").to("cuda:0").eval()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         pipe = SlidePipeline(nets["f16x3"], vis, n_clusters=8, sub_batch=500)
