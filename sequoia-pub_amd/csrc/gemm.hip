@@ -28,6 +28,8 @@ bool sq_conv_halo_eligible(const GemmArgs& a, int dtype);
 int sq_launch_conv_halo(const GemmArgs& a, hipStream_t stream);
 bool sq_gemm_w4_eligible(const GemmArgs& a, int dtype);
 int sq_launch_gemm_w4(const GemmArgs& a, hipStream_t stream);
+bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype);
+int sq_launch_gemm_p8(const GemmArgs& a, hipStream_t stream);
 bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype);
 int sq_launch_gemm_ring(const GemmArgs& a, hipStream_t stream);
 
@@ -559,6 +561,8 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
         // long-K products with enough 256 x 128 tiles: three-stage ring kernel (gemm_ring.hip); SQ_GEMM_RING=0 turns it off
         // 3x3 / stride-1 convolutions with enough 256 x 128 tiles: input tile resident in LDS (conv_halo.hip)
         if (g_force_tile == 0 && a.splitk == 1 && sq_conv_halo_eligible(a, SQ_BF16)) return sq_launch_conv_halo(a, stream);
+        // large plain products: 256 x 256 x 64 tile, eight phases per pair of K-tiles (gemm_p8.hip); tile 88 forces it
+        if (a.splitk == 1 && a.N % 8 == 0 && !a.conv && (g_force_tile == 88 || (g_force_tile == 0 && sq_gemm_p8_eligible(a, SQ_BF16)))) return sq_launch_gemm_p8(a, stream);
         // large products: 256 x 256 tile on four waves, 128 x 128 per wave (gemm_w4.hip); tile 55 forces it
         if (a.splitk == 1 && a.N % 8 == 0 && (g_force_tile == 55 || (g_force_tile == 0 && sq_gemm_w4_eligible(a, SQ_BF16)))) return sq_launch_gemm_w4(a, stream);
         if (g_use_ring < 0) { const char* e = getenv("SQ_GEMM_RING"); g_use_ring = (e && e[0] == '0') ? 0 : 1; }
@@ -579,6 +583,7 @@ int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return laun
 
 int g_x3_small_max_k = -1, g_x3_halo = -1;
 extern int g_w4_waves;
+extern int g_p8_sched;
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
@@ -587,6 +592,7 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
     else if (key == 7) g_x3_small_max_k = value;
+    else if (key == 10) g_p8_sched = value;          // gemm_p8.hip: schedule variant
     else if (key == 9) g_w4_waves = value;           // gemm_w4.hip: 4 or 8 waves per 256 x 256 tile
     else if (key == 8) g_x3_halo = value;            // split-mode 3x3: 0 = implicit GEMM only     // split-mode product: K up to this takes the 128-row shape (-1 = default / environment)
     else return SQ_ERR_ARG;

@@ -1,0 +1,339 @@
+// 256 x 256 x 64 block tile, eight waves (2 x 4, 128 x 64 per wave), 16x16x32 MFMAs, TWO LDS buffers of four 16 KiB half-tiles,
+// eight phases per pair of K-tiles -- the NT engine's kernel for large bf16 products (UNI ViT-L/16, the spatial path, ViS
+// inference at large batch, the ResNet's plain 1x1 products in bf16 mode).
+//
+// Why another shape (gemm_w4.hip is 256 x 256 x 32, four stages, 32x32x16 MFMAs): a 32-deep K-tile is a 64-byte row -- every
+// operand request touches HALF a 128-byte line and the other half is wanted one stage later, when L1 has dropped it
+// (K-tile-major operands took gemm_w4 from 829 to 1170 TF on 8192^3, addressing only).  A 64-deep tile
+// makes every row a whole line with the operands left row-major, at the price of 128 KiB for TWO buffers; with two buffers
+// the load -> use distance comes from splitting the tile instead: a K-tile is four half-tiles (A even / odd 64-row groups,
+// B even / odd 32-column groups), each phase reads ONE half-tile's fragments, multiplies ONE 64 x 32 quadrant of the wave's
+// patch (16 MFMAs) and re-stages the half-tile that the previous phase read last -- so a slot is refilled one phase after
+// its last read and every request has six to seven phases (~2000 clocks) to land:
+//
+//   phase  reads (ds_read_b128)         multiplies     stages (2 LDS-DMA instructions per thread)
+//   1      B_0 (4), A_0 (8) of tile t   A_0 x B_0      B_0 of tile t+1  (slot read last in phase 4 of tile t-1)
+//   2      B_1 (4)                      A_0 x B_1      A_0 of tile t+2
+//   3      A_1 (8)                      A_1 x B_1      B_1 of tile t+2
+//   4      B_0 (4)                      A_1 x B_0      A_1 of tile t+2;  s_waitcnt vmcnt(6): tile t+1 has landed
+//
+// The two wave rows run ONE BARRIER apart (waves 4-7 take an extra s_barrier in front of the loop, waves 0-3 one behind
+// it): while one group of four waves -- one per SIMD -- issues its fragment reads and LDS-DMA, the other group's MFMAs own
+// the matrix pipes (s_setprio 1 around them), and vice versa.  Never a vmcnt(0) inside the loop; a wave's fragment reads are
+// retired (lgkmcnt(0)) before the barrier that lets the other group re-stage the slot.
+// LDS image: 1 KiB sub-tiles of [16 rows][32 k], byte ^= ((byte >> 9) & 1) << 5 inside a sub-tile (rows 8-15 swap their
+// 32-byte halves): conflict-free 16-lane groups for the 16x16x32 fragment reads; with LDS-DMA the permutation sits on the
+// SOURCE address.  Half-tile A_a = block rows with (m >> 6) & 1 == a, B_b = columns with (n >> 5) & 1 == b, so that a wave's
+// 128 x 64 patch is contiguous in C although each of its quadrants lives in its own half-tile.
+// Epilogue: per-wave 32 x 64 fp32 slabs through LDS, 16-byte accesses, bias / residual / ReLU / GELU / bf16 copy as gemm_w4.hip.
+#include "gemm.h"
+#include "gemm_epi.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr uint32_t OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_base, uint32_t voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_base, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ u32x4 lds_read128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
+constexpr int HALF_BYTES = 128 * BK * 2;         // 16 KiB: 128 rows x 64 k
+constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A_0 A_1 B_0 B_1
+constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 128 KiB (the epilogue slabs need 64 KiB of it)
+constexpr int SLAB_BYTES = 32 * 64 * 4;          // one wave's 32 x 64 fp32 slab
+
+template <int EPI, int SCHED>
+__global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int t;
+    {   // each XCD (block id % 8) walks a contiguous run of tiles
+        const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    const int z = blockIdx.z;
+
+    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.sA;
+    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B) + (long long)z * p.sB;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(p.a_bytes - (size_t)z * p.sA * 2), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(p.b_bytes - (size_t)z * p.sB * 2), 0x00020000);
+
+    // ---- staging geometry.  Wave w stages row group w (16 LDS rows) of a half-tile, both 32-deep halves: two instructions
+    // that together request the whole 128-byte line of each of the 16 rows.  Lane l lands at byte 16 l of the 1 KiB
+    // sub-tile = LDS row l >> 2, PHYSICAL chunk l & 3; it must hold LOGICAL chunk (l & 3) ^ 2 [rows 8-15].
+    const int s_lr = lane >> 2;
+    const int s_ck = (lane & 3) ^ ((lane >> 5) << 1);
+    const int s_R = wave * 16 + s_lr;                                     // LDS row of the half-tile
+    uint32_t a_src[2], b_src[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = m0 + (s_R >> 6) * 128 + h * 64 + (s_R & 63);       // half-tile A_h: rows with (m >> 6) & 1 == h
+        const int n = n0 + (s_R >> 5) * 64 + h * 32 + (s_R & 31);        // half-tile B_h: columns with (n >> 5) & 1 == h
+        a_src[h] = m < p.M ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(s_ck * 8)) * 2u : OOB;
+        b_src[h] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(s_ck * 8)) * 2u : OOB;
+    }
+    const int nk = (p.K + BK - 1) / BK;
+    // slot: 0 A_0, 1 A_1, 2 B_0, 3 B_1.  Tiles behind the last one (and the ragged end of K: K % 8 == 0, whole chunks) fetch
+    // nothing -- the instruction is still issued so that the counted waits stay uniform.
+    auto stage = [&](int kt, int slot, int buf) {
+        char* dst = smem + buf * BUF_BYTES + slot * HALF_BYTES + wave * 2048;
+        const uint32_t src = slot < 2 ? a_src[slot & 1] : b_src[slot & 1];
+        const auto rs = slot < 2 ? rsA : rsB;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const bool ok = kt < nk && k0 + kh * 32 + s_ck * 8 < p.K;
+            glds16(rs, dst + kh * 1024, ok ? src : OOB, (k0 + kh * 32) * 2);
+        }
+    };
+
+    // ---- fragment geometry (16x16x32: lane = (row l & 15, k group l >> 4), 8 consecutive k = 16 bytes)
+    const int f_r = lane & 15, f_kg = lane >> 4;
+    const int f_byte = (f_r * 64 + f_kg * 16) ^ ((f_r >> 3) << 5);
+    // A_a m-fragment ii (0..3): LDS rows wr * 64 + ii * 16 -> row group wr * 4 + ii;  B_b n-fragment jj (0..1): row group wc * 2 + jj
+    const int fa_base = (wr * 4) * 2048 + f_byte, fb_base = 2 * HALF_BYTES + (wc * 2) * 2048 + f_byte;
+
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 fa[4][2], fb[2][2];
+    auto read_a = [&](int buf, int a) {
+        const char* s = smem + buf * BUF_BYTES + a * HALF_BYTES + fa_base;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[ii][ks] = lds_read128(s + ii * 2048 + ks * 1024);
+    };
+    auto read_b = [&](int buf, int b) {
+        const char* s = smem + buf * BUF_BYTES + b * HALF_BYTES + fb_base;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[jj][ks] = lds_read128(s + jj * 2048 + ks * 1024);
+    };
+    auto mma = [&](auto ac, auto bc) {
+        constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    union { u32x4 u; bf16x8 h; } ua, ub;
+                    ua.u = fa[ii][ks]; ub.u = fb[jj][ks];
+                    acc[a * 4 + ii][b * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.h, ub.h, acc[a * 4 + ii][b * 2 + jj], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // one phase's ending: [SCHED 0: this wave's fragment reads are complete before] the barrier that lets the other group
+    // run its load segment; then the multiply; then the barrier that hands the pipes to the other group.
+    // SCHED 1 waits for the fragments BEHIND the barrier (their latency overlaps the barrier wait); it is safe because
+    // that schedule re-stages a slot TWO phases after its last read (below).
+#define P8_SYNC_MMA(AC, BC)                                                          \
+    if constexpr (SCHED == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    __builtin_amdgcn_s_barrier();                                                    \
+    if constexpr (SCHED != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    mma(AC{}, BC{});                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    __builtin_amdgcn_s_barrier();                                                    \
+    __builtin_amdgcn_sched_barrier(0)
+
+    // four phases of tile kt in buffer `buf` (compile-time).  Last reads of a tile's slots: A_0 phase 1, B_1 phase 2, A_1 phase
+    // 3, B_0 phase 4.  SCHED 0 refills a slot ONE phase later (three half-tiles in flight behind the wait, vmcnt(6)); SCHED 1
+    // TWO phases later (two in flight, vmcnt(4)).
+    auto tile_phases = [&](int kt, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        read_b(buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf, 0);
+        if constexpr (SCHED == 0) stage(kt + 1, 2, buf ^ 1); else stage(kt + 1, 1, buf ^ 1);
+        P8_SYNC_MMA(I0, I0);
+        read_b(buf, 1);
+        if constexpr (SCHED == 0) stage(kt + 2, 0, buf); else stage(kt + 1, 2, buf ^ 1);
+        P8_SYNC_MMA(I0, I1);
+        read_a(buf, 1);
+        if constexpr (SCHED == 0) stage(kt + 2, 3, buf); else stage(kt + 2, 0, buf);
+        P8_SYNC_MMA(I1, I1);
+        read_b(buf, 0);
+        if constexpr (SCHED == 0) {
+            stage(kt + 2, 1, buf);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // everything up to B_0 of tile kt + 1 has landed (this wave's part)
+        } else {
+            stage(kt + 2, 3, buf);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        P8_SYNC_MMA(I1, I0);
+    };
+
+    // prologue: tile 0 complete, then what the steady state would have issued during "tile -1"
+    stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(0, 1, 0);
+    if constexpr (SCHED == 0) {
+        stage(1, 0, 1); stage(1, 3, 1); stage(1, 1, 1);           // A_0, B_1, A_1 of tile 1
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        stage(1, 0, 1); stage(1, 3, 1);                            // A_0, B_1 of tile 1
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3
+    for (int kt = 0; kt < nk; kt += 2) {
+        tile_phases(kt, I0{});
+        if (kt + 1 < nk) tile_phases(kt + 1, I1{});
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing empty loads have written their zeros
+    __syncthreads();                                    // all fragment reads done: the buffers become the epilogue slabs
+#undef P8_SYNC_MMA
+
+    // ---- epilogue.  C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r.  Wave patch: rows m0 + wr*128 .. +128,
+    // columns n0 + wc*64 .. +64; slab s = m-fragments 2s, 2s+1 (32 rows) x 64 columns, private to the wave.
+    float* slab = reinterpret_cast<float*>(smem + wave * SLAB_BYTES);
+    const int e_c8 = lane & 7, e_r8 = lane >> 3;         // read-out: 8 lanes cover a slab row (64 columns), 8 rows per pass
+    const int e_n = n0 + wc * 64 + e_c8 * 8;
+    const int e_cnt = min(8, p.N - e_n);
+    const bool fast = (EPI == 0 || EPI == 1) && p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && !p.Cpre && !p.gelu_grad_of && !p.ln64_g;
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (fast && p.bias) {
+        const float* bsrc = p.bias + (long long)z * p.sBias + e_n;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(bsrc), t1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = t0[e]; bias8[4 + e] = t1[e]; }
+    }
+    const float* res32 = (fast && p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
+    const bf16_t* res16 = (fast && p.res && p.res_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes : nullptr;
+    float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
+    bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
+    auto slab_out = [&](auto sc) {                       // compile-time slab index: a run-time one would push the accumulators to scratch
+        constexpr int s = decltype(sc)::value;
+        const int mrow0 = m0 + wr * 128 + s * 32;
+        float aux[4][8];
+        if (fast) {                                      // residual rows requested before the slab is written
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) aux[u][e] = 0.f;
+                const int m = mrow0 + u * 8 + e_r8;
+                if (m < p.M) {
+                    if (res16) {
+                        const u32x4 tt = *reinterpret_cast<const u32x4*>(res16 + (long long)m * p.ldres + e_n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { aux[u][2 * e] = __uint_as_float(tt[e] << 16); aux[u][2 * e + 1] = __uint_as_float(tt[e] & 0xffff0000u); }
+                    } else if (res32) {
+                        const float* src = res32 + (long long)m * p.ldres + e_n;
+                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { aux[u][e] = t0[e]; aux[u][4 + e] = t1[e]; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(h * 16 + f_kg * 4 + r) * 64 + j * 16 + f_r] = acc[2 * s + h][j][r];
+        // the slab is private to the wave: its own LDS writes are ordered before its reads (lgkmcnt), no barrier
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = u * 8 + e_r8;
+            const int m = mrow0 + row;
+            if (m >= p.M || e_cnt <= 0) continue;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8 + 4);
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            if (!fast) {
+                epi_apply<EPI, true>(p, z, m, e_n, v, e_cnt, p.vec_epi != 0 && e_cnt == 8);
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (p.alpha * v[e] + bias8[e]) + aux[u][e];
+            if ((EPI & 1) && p.act == SQ_ACT_GELU) {                     // same erf form as epi_apply<EPI, true>
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sq_gelu<true>(v[e]);
+            } else if (p.act == SQ_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (c32) {
+                float* d = c32 + (long long)m * p.ldc + e_n;
+                *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+            const u32x4 packed = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            if (c16p) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = packed;
+            if (p.C2) *reinterpret_cast<u32x4*>(p.C2 + (long long)z * p.sC2 + (long long)m * p.ldc2 + e_n) = packed;   // bf16 operand copy
+        }
+    };
+    slab_out(std::integral_constant<int, 0>{});
+    slab_out(std::integral_constant<int, 1>{});
+    slab_out(std::integral_constant<int, 2>{});
+    slab_out(std::integral_constant<int, 3>{});
+}
+
+}  // namespace
+
+// true when the eight-phase 256 x 256 x 64 kernel takes the product: bf16, plain (no convolution view), K in whole 16-byte
+// chunks, enough tiles to give (nearly) every CU one, and only the epilogues its prefetching fast path covers
+bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype) {
+    if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.ln64_g || a.rowbias || a.Cpre || a.gelu_grad_of || !a.vec_epi) return false;
+    static int on = -1, min_tiles = 0, min_k = 0;
+    if (on < 0) {
+        const char* e = getenv("SQ_GEMM_P8");
+        on = (e && e[0] == '0') ? 0 : 1;          // SQ_GEMM_P8=0: back to gemm_w4.hip (the A/B of tools/gemm_probe.py p8)
+        const char* mt = getenv("SQ_GEMM_P8_MIN_TILES");
+        min_tiles = mt ? atoi(mt) : 232;
+        const char* mk = getenv("SQ_GEMM_P8_MIN_K");
+        min_k = mk ? atoi(mk) : 512;
+    }
+    if (!on) return false;
+    const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.batch;
+    return a.K % 8 == 0 && a.K >= min_k && a.N % BN == 0 && tiles >= min_tiles;
+}
+
+int g_p8_sched = -1;               // sq_dbg_set key 10 (probes): 0 / 1, -1 = environment (SQ_GEMM_P8_SCHED) or the default
+namespace {
+template <int EPI, int SCHED>
+int launch_p8(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+    static SqDevOnce attr;       // hipFuncSetAttribute is per device
+    if (attr.needed()) {
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_p8_kernel<EPI, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr.done();
+    }
+    hipLaunchKernelGGL((gemm_p8_kernel<EPI, SCHED>), grid, dim3(NT), LDS_BYTES, stream, a);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+}  // namespace
+
+int sq_launch_gemm_p8(const GemmArgs& a, hipStream_t stream) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const dim3 grid(tiles, 1, a.batch);
+    static int env_sched = -1;
+    if (env_sched < 0) { const char* e = getenv("SQ_GEMM_P8_SCHED"); env_sched = e ? atoi(e) : 1; }
+    if ((g_p8_sched >= 0 ? g_p8_sched : env_sched) == 0) return a.act == SQ_ACT_GELU ? launch_p8<1, 0>(a, grid, stream) : launch_p8<0, 0>(a, grid, stream);
+    return a.act == SQ_ACT_GELU ? launch_p8<1, 1>(a, grid, stream) : launch_p8<0, 1>(a, grid, stream);
+}

@@ -191,6 +191,46 @@ def test_four_stage_256_tile_variant_matches_default_tile(M, N, K, act, waves):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K,act,out", [(256 * 9 + 37, 512, 320, 2, "bf16"), (700, 256 + 64, 1024, 1, "bf16"), (3000, 768, 72, 0, "f32"),
+                                           (256 * 40, 1024, 4096, 0, "f32")])
+@pytest.mark.parametrize("sched", [0, 1])
+def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched):
+    """gemm_p8.hip (256 x 256 x 64 tile, two buffers of four half-tiles, eight phases per pair of K-tiles, the two wave rows one
+    barrier apart, 16x16x32 MFMAs), forced through the experiment knob: ragged M / N / K (an odd number of K-tiles, a K-tile
+    with a single 16-byte chunk), bias, bf16 residual, ReLU / GELU, bf16 / fp32 output against the fp32 product of the same
+    bf16 operands and against the default tile (another MFMA shape sums K in another order: close, not bit-equal); run
+    three times -- a schedule race would show as run-to-run differences."""
+    _lib.require_gpu()
+    lib = _lib.lib()
+    lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().bfloat16()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda().bfloat16()
+    odt, ocode = (torch.bfloat16, _lib.SQ_BF16) if out == "bf16" else (torch.float32, _lib.SQ_F32)
+    outs = []
+    lib.sq_dbg_set(10, sched)            # 0: slots refilled one phase after their last read, fragment waits in front of the barrier; 1: two phases, behind it
+    try:
+        for tile in (22, 88, 88, 88):
+            lib.sq_dbg_set(0, tile)
+            C = torch.full((M, N), float("nan"), device="cuda", dtype=odt)
+            _lib.check(lib.sq_linear(_lib.SQ_BF16, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(bias), _lib.ptr(res), N, _lib.SQ_BF16, act,
+                                     _lib.ptr(C), ocode, N, M, N, K, None, 0, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            outs.append(C.float())
+    finally:
+        lib.sq_dbg_set(0, 0)
+        lib.sq_dbg_set(10, -1)
+    pre = A.float() @ W.float().T + bias + res.float()
+    ref = torch.relu(pre) if act == 2 else torch.nn.functional.gelu(pre) if act == 1 else pre
+    assert torch.isfinite(outs[1]).all()
+    tol = 1e-2 if out == "bf16" else 2e-3 if act == 1 else 1e-5
+    assert rel_err(outs[1].cpu(), ref.cpu()) < tol, rel_err(outs[1].cpu(), ref.cpu())
+    assert rel_err(outs[1].cpu(), outs[0].cpu()) < tol
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
+
+
 @pytest.mark.parametrize("M,N,K", [(70000, 256, 1024), (65536 + 77, 128, 576)])
 def test_ring_variant_matches_default_tile(M, N, K):
     """The three-stage 256 x 128 ring kernel (gemm_ring.hip) walks K in the same order with the same MFMA as the

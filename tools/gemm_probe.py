@@ -25,27 +25,30 @@ def time_fn(fn, iters=30):
     return a.elapsed_time(b) / iters * 1e3   # us
 
 
-def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6)):
+def probe(M, N, K, dtype, tiles=(22, 21, 12, 11), dbgs=(0, 1, 2, 4, 3, 6), out_bf16=False, scheds=(None,)):
     tdt = torch.bfloat16 if dtype == _lib.SQ_BF16 else torch.float32
     A = torch.randn(M, K, device="cuda").to(tdt)
     W = torch.randn(N, K, device="cuda").to(tdt)
-    C = torch.empty(M, N, device="cuda")
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
     flops = 2.0 * M * N * K
     t = time_fn(lambda: torch.matmul(A, W.T))
     print(f"M={M} N={N} K={K} {tdt}: torch.matmul {t:8.1f} us {flops / t / 1e6:8.1f} TF", flush=True)
     for tile in tiles:
+      for sched in (scheds if tile == 88 else (None,)):
         for dbg in dbgs:
             lib.sq_dbg_set(0, tile)
             lib.sq_dbg_set(1, dbg)
-            fn = lambda: _lib.check(lib.sq_linear(dtype, _lib.ptr(A), K, _lib.ptr(W), K, None, None, 0, 0, 0, _lib.ptr(C), 0, N, M, N, K, _lib.ptr(WS), WS.numel(), _lib.stream_ptr()))
+            lib.sq_dbg_set(10, -1 if sched is None else sched)
+            fn = lambda: _lib.check(lib.sq_linear(dtype, _lib.ptr(A), K, _lib.ptr(W), K, None, None, 0, 0, 0, _lib.ptr(C), 1 if out_bf16 else 0, N, M, N, K, _lib.ptr(WS), WS.numel(), _lib.stream_ptr()))
             t = time_fn(fn)
             err = ""
             if dbg == 0 and M * N <= (1 << 28):
                 ref = torch.matmul(A, W.T).float()
-                err = f"  max rel err vs torch {float((C - ref).abs().max() / ref.abs().max()):.2e}"
-            print(f"   tile {tile} dbg {dbg}: {t:8.1f} us {flops / t / 1e6:8.1f} TF{err}", flush=True)
+                err = f"  max rel err vs torch {float((C.float() - ref).abs().max() / ref.abs().max()):.2e}"
+            print(f"   tile {tile}{'' if sched is None else ' sched %d' % sched} dbg {dbg}: {t:8.1f} us {flops / t / 1e6:8.1f} TF{err}", flush=True)
     lib.sq_dbg_set(0, 0)
     lib.sq_dbg_set(1, 0)
+    lib.sq_dbg_set(10, -1)
 
 
 if __name__ == "__main__":
@@ -58,6 +61,14 @@ if __name__ == "__main__":
         # gemm_w4.hip with K-tile-major operand addressing (dbg 32: weights, 96: weights and activations), timing only
         for M, N, K in [(8192, 8192, 8192), (102400, 1024, 1024), (50432, 4096, 1024), (50432, 1024, 4096), (50432, 3072, 1024), (102400, 2048, 2048)]:
             probe(M, N, K, _lib.SQ_BF16, tiles=(55,), dbgs=(0, 32, 96, 0, 32, 96))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8":
+        # gemm_p8.hip (tile 88: 256 x 256 x 64, eight phases) against the engine's pick (0), gemm_w4.hip (55) and hipBLASLt
+        for M, N, K in [(8192, 8192, 8192), (4096, 4096, 4096), (50432, 4096, 1024), (50432, 1024, 4096), (50432, 3072, 1024), (50432, 1024, 1024),
+                        (102400, 2048, 2048), (102400, 1024, 1024), (6400, 1024, 1024), (24500, 2048, 1024)]:
+            probe(M, N, K, _lib.SQ_BF16, tiles=(0, 55, 88, 88), dbgs=(0,), scheds=(0, 1))
+        for M, N, K in [(50432, 4096, 1024), (50432, 3072, 1024)]:           # bf16 output (what the UNI blocks write)
+            probe(M, N, K, _lib.SQ_BF16, tiles=(55, 88), dbgs=(0,), out_bf16=True, scheds=(0, 1))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "w4":
         for M, N, K in [(8192, 8192, 8192), (4096, 4096, 4096), (102400, 1024, 1024), (50432, 4096, 1024), (50432, 1024, 4096), (24500, 512, 4608),
