@@ -61,6 +61,8 @@ struct GemmArgs {
     const void* B2 = nullptr; size_t b2_bytes = 0; int ldb2 = 0; int K2 = 0;           // [N, K2] planes, plB apart, b_tiled as B
     const float* bias2 = nullptr; const float* colscale2 = nullptr;
     int dH = 0, dW = 0, dOH = 0, dOW = 0, dstride = 1;
+    int tile_group_m = 0;              // gemm_p8.hip: tile rows per group of the tile walk (set by its launcher)
+    int skew_cycles = 0;               // gemm_p8.hip, persistent form: start-up delay per skew step (set by its launcher)
     int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };
 

@@ -583,7 +583,7 @@ int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return laun
 
 int g_x3_small_max_k = -1, g_x3_halo = -1;
 extern int g_w4_waves;
-extern int g_p8_sched;
+extern int g_p8_sched, g_p8_group_m, g_p8_skew;
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
@@ -592,6 +592,8 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
     else if (key == 7) g_x3_small_max_k = value;
+    else if (key == 12) g_p8_skew = value;           // gemm_p8.hip, persistent form: start-up skew in cycles per step
+    else if (key == 11) g_p8_group_m = value;        // gemm_p8.hip: tile rows per group of the tile walk
     else if (key == 10) g_p8_sched = value;          // gemm_p8.hip: schedule variant
     else if (key == 9) g_w4_waves = value;           // gemm_w4.hip: 4 or 8 waves per 256 x 256 tile
     else if (key == 8) g_x3_halo = value;            // split-mode 3x3: 0 = implicit GEMM only     // split-mode product: K up to this takes the 128-row shape (-1 = default / environment)

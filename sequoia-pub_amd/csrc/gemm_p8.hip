@@ -25,7 +25,15 @@
 // 32-byte halves): conflict-free 16-lane groups for the 16x16x32 fragment reads; with LDS-DMA the permutation sits on the
 // SOURCE address.  Half-tile A_a = block rows with (m >> 6) & 1 == a, B_b = columns with (n >> 5) & 1 == b, so that a wave's
 // 128 x 64 patch is contiguous in C although each of its quadrants lives in its own half-tile.
-// Epilogue: per-wave 32 x 64 fp32 slabs through LDS, 16-byte accesses, bias / residual / ReLU / GELU / bf16 copy as gemm_w4.hip.
+// Epilogue: per-wave 16 x 64 fp32 slabs through LDS, 16-byte accesses, bias / residual / ReLU / GELU / bf16 copy as gemm_w4.hip.
+// PERSISTENT form (one block per CU; block i of the 32 an XCD runs takes tiles i, i + 32, ... of the XCD's run): with K = 1024 a tile's
+// 256 x 256 results are a third of its time when every CU stores them in the same few microseconds (tools/gemm_probe.py p8a:
+// 50432 x 4096 x 1024 with fp32 results 534 us, 367 us without the stores = an HBM write burst at 4.9 TB/s).  The persistent
+// block requests the NEXT tile's first operands before it writes the current tile's results (the slabs live in the 32 KiB
+// the two buffers leave free): their latency hides behind the epilogue, +2..5 % on the K = 1024 shapes.  The burst itself
+// stays: the next tile's first wait is a counted vmcnt, and a counted wait cannot tell loads from stores -- on gfx950 they
+// retire OUT OF ORDER with respect to each other (tools/vmcnt_probe.hip: 90 % of the lanes see a sentinel when a wave
+// waits vmcnt(NS) for a load issued in front of NS stores), so it has to cover the stores too.
 #include "gemm.h"
 #include "gemm_epi.h"
 
@@ -47,24 +55,53 @@ constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
 constexpr int HALF_BYTES = 128 * BK * 2;         // 16 KiB: 128 rows x 64 k
 constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A_0 A_1 B_0 B_1
 constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 128 KiB (the epilogue slabs need 64 KiB of it)
-constexpr int SLAB_BYTES = 32 * 64 * 4;          // one wave's 32 x 64 fp32 slab
+constexpr int SLAB_BYTES = 16 * 64 * 4;          // one wave's 16 x 64 fp32 slab
 
-template <int EPI, int SCHED>
+template <int EPI, bool PERSIST, bool DBG>
 __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    const int dbg = DBG ? p.dbg : 0;     // ablation switches (tools/gemm_probe.py p8a): 1 no stores, 2 no LDS-DMA inside the loop, 4 no MFMA, 8 no fragment reads
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
-    int t;
-    {   // each XCD (block id % 8) walks a contiguous run of tiles
-        const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int z = PERSIST ? 0 : blockIdx.z;
+    // each XCD (block id % 8) owns a contiguous run of tiles ...
+    const int xcd = blockIdx.x & 7;
+    auto run_start = [&](int x) { const int q = nwg >> 3, r = nwg & 7; return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q; };
+    auto run_count = [&](int x) { return (nwg >> 3) + (x < (nwg & 7) ? 1 : 0); };
+    // ... and inside the run takes the tiles in groups of `gm` tile rows, column by column: the 32 blocks an XCD runs at a time
+    // then cover gm row panels x 32 / gm column panels instead of one row panel x 32 column panels -- per K-tile
+    // (gm + 32 / gm) x 32 KiB of distinct operand bytes instead of 33 x 32 KiB, so most staging requests hit the XCD's L2
+    // (38 TB/s, tools/stage_probe.hip) instead of going to the memory-side cache (~10 TB/s)
+    int m0 = 0, n0 = 0;
+    auto tile_coords = [&](int t, int& m0_, int& n0_) {
+        const int gm = p.tile_group_m > 0 ? p.tile_group_m : 1;
+        const int per_group = gm * tiles_n;
+        const int g = t / per_group, first_m = g * gm;
+        const int gsz = min(tiles_m - first_m, gm);
+        const int in_g = t - g * per_group;
+        m0_ = (first_m + in_g % gsz) * BM;
+        n0_ = (in_g / gsz) * BN;
+    };
+    // persistent form: block (xcd, i) of the G blocks an XCD runs takes tiles i, i + G, i + 2 G, ... of the XCD's run -- the order
+    // the dispatcher would have handed them out in
+    const int G = PERSIST ? (int)(gridDim.x >> 3) : 1;
+    int idx = blockIdx.x >> 3;
+    if (idx >= run_count(xcd)) return;
+    int t_cur = run_start(xcd) + idx;
+    if constexpr (PERSIST) {
+        // experiment knob (tools/gemm_probe.py p8p): a start-up delay of (i mod 4) steps, to let the stores of some CUs run under
+        // the K loops of others -- does not pay (launcher comment)
+        if (p.skew_cycles > 0) {
+            const long long t0 = __builtin_readcyclecounter();
+            const long long wait = (long long)(idx & 3) * p.skew_cycles;
+            while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
     }
-    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-    const int z = blockIdx.z;
+    tile_coords(t_cur, m0, n0);
 
     const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.sA;
     const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B) + (long long)z * p.sB;
@@ -78,17 +115,22 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     const int s_ck = (lane & 3) ^ ((lane >> 5) << 1);
     const int s_R = wave * 16 + s_lr;                                     // LDS row of the half-tile
     uint32_t a_src[2], b_src[2];
+    auto set_src = [&](int m0_, int n0_) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int m = m0 + (s_R >> 6) * 128 + h * 64 + (s_R & 63);       // half-tile A_h: rows with (m >> 6) & 1 == h
-        const int n = n0 + (s_R >> 5) * 64 + h * 32 + (s_R & 31);        // half-tile B_h: columns with (n >> 5) & 1 == h
-        a_src[h] = m < p.M ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(s_ck * 8)) * 2u : OOB;
-        b_src[h] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(s_ck * 8)) * 2u : OOB;
-    }
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0_ + (s_R >> 6) * 128 + h * 64 + (s_R & 63);   // half-tile A_h: rows with (m >> 6) & 1 == h
+            const int n = n0_ + (s_R >> 5) * 64 + h * 32 + (s_R & 31);    // half-tile B_h: columns with (n >> 5) & 1 == h
+            a_src[h] = m < p.M ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(s_ck * 8)) * 2u : OOB;
+            b_src[h] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(s_ck * 8)) * 2u : OOB;
+        }
+    };
+    set_src(m0, n0);
     const int nk = (p.K + BK - 1) / BK;
     // slot: 0 A_0, 1 A_1, 2 B_0, 3 B_1.  Tiles behind the last one (and the ragged end of K: K % 8 == 0, whole chunks) fetch
     // nothing -- the instruction is still issued so that the counted waits stay uniform.
+    bool in_loop = false;
     auto stage = [&](int kt, int slot, int buf) {
+        if ((dbg & 2) && in_loop) return;
         char* dst = smem + buf * BUF_BYTES + slot * HALF_BYTES + wave * 2048;
         const uint32_t src = slot < 2 ? a_src[slot & 1] : b_src[slot & 1];
         const auto rs = slot < 2 ? rsA : rsB;
@@ -99,6 +141,11 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
             glds16(rs, dst + kh * 1024, ok ? src : OOB, (k0 + kh * 32) * 2);
         }
     };
+    // first operands of a tile: K-tile 0 complete, then what the steady state would have issued during "K-tile -1"
+    auto stage_first = [&]() {
+        stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(0, 1, 0);
+        stage(1, 0, 1); stage(1, 3, 1);                            // A_0, B_1 of K-tile 1
+    };
 
     // ---- fragment geometry (16x16x32: lane = (row l & 15, k group l >> 4), 8 consecutive k = 16 bytes)
     const int f_r = lane & 15, f_kg = lane >> 4;
@@ -107,13 +154,9 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     const int fa_base = (wr * 4) * 2048 + f_byte, fb_base = 2 * HALF_BYTES + (wc * 2) * 2048 + f_byte;
 
     f32x4v acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
-    u32x4 fa[4][2], fb[2][2];
+    u32x4 fa[4][2] = {}, fb[2][2] = {};
     auto read_a = [&](int buf, int a) {
+        if (dbg & 8) return;
         const char* s = smem + buf * BUF_BYTES + a * HALF_BYTES + fa_base;
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
@@ -121,6 +164,7 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
             for (int ks = 0; ks < 2; ++ks) fa[ii][ks] = lds_read128(s + ii * 2048 + ks * 1024);
     };
     auto read_b = [&](int buf, int b) {
+        if (dbg & 8) return;
         const char* s = smem + buf * BUF_BYTES + b * HALF_BYTES + fb_base;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -129,6 +173,12 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     };
     auto mma = [&](auto ac, auto bc) {
         constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
+        if (dbg & 4) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) asm volatile("" ::"v"(fa[ii][0]), "v"(fa[ii][1]));
+            asm volatile("" ::"v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[1][0]), "v"(fb[1][1]));
+            return;
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -144,154 +194,163 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    // one phase's ending: [SCHED 0: this wave's fragment reads are complete before] the barrier that lets the other group
-    // run its load segment; then the multiply; then the barrier that hands the pipes to the other group.
-    // SCHED 1 waits for the fragments BEHIND the barrier (their latency overlaps the barrier wait); it is safe because
-    // that schedule re-stages a slot TWO phases after its last read (below).
-#define P8_SYNC_MMA(AC, BC)                                                          \
-    if constexpr (SCHED == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
-    __builtin_amdgcn_sched_barrier(0);                                               \
-    __builtin_amdgcn_s_barrier();                                                    \
-    if constexpr (SCHED != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
-    __builtin_amdgcn_sched_barrier(0);                                               \
-    mma(AC{}, BC{});                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                               \
-    __builtin_amdgcn_s_barrier();                                                    \
+    // one phase's ending: the barrier that lets the other group run its load segment; the fragments are waited for BEHIND it
+    // (their latency overlaps the barrier wait -- safe because a slot is re-staged TWO phases after its last read); the
+    // multiply; the barrier that hands the pipes to the other group
+#define P8_SYNC_MMA(AC, BC)                                          \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    __builtin_amdgcn_s_barrier();                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    mma(AC{}, BC{});                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    __builtin_amdgcn_s_barrier();                                    \
     __builtin_amdgcn_sched_barrier(0)
 
-    // four phases of tile kt in buffer `buf` (compile-time).  Last reads of a tile's slots: A_0 phase 1, B_1 phase 2, A_1 phase
-    // 3, B_0 phase 4.  SCHED 0 refills a slot ONE phase later (three half-tiles in flight behind the wait, vmcnt(6)); SCHED 1
-    // TWO phases later (two in flight, vmcnt(4)).
+    // four phases of K-tile kt in buffer `buf` (compile-time).  Last reads of a K-tile's slots: A_0 phase 1, B_1 phase 2, A_1
+    // phase 3, B_0 phase 4; each is refilled two phases later: two half-tiles in flight behind the wait of phase 4.
     auto tile_phases = [&](int kt, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         read_b(buf, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(buf, 0);
-        if constexpr (SCHED == 0) stage(kt + 1, 2, buf ^ 1); else stage(kt + 1, 1, buf ^ 1);
+        stage(kt + 1, 1, buf ^ 1);
         P8_SYNC_MMA(I0, I0);
         read_b(buf, 1);
-        if constexpr (SCHED == 0) stage(kt + 2, 0, buf); else stage(kt + 1, 2, buf ^ 1);
+        stage(kt + 1, 2, buf ^ 1);
         P8_SYNC_MMA(I0, I1);
         read_a(buf, 1);
-        if constexpr (SCHED == 0) stage(kt + 2, 3, buf); else stage(kt + 2, 0, buf);
+        stage(kt + 2, 0, buf);
         P8_SYNC_MMA(I1, I1);
         read_b(buf, 0);
-        if constexpr (SCHED == 0) {
-            stage(kt + 2, 1, buf);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // everything up to B_0 of tile kt + 1 has landed (this wave's part)
-        } else {
-            stage(kt + 2, 3, buf);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
+        stage(kt + 2, 3, buf);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything up to B_0 of K-tile kt + 1 has landed (this wave's part)
         P8_SYNC_MMA(I1, I0);
     };
 
-    // prologue: tile 0 complete, then what the steady state would have issued during "tile -1"
-    stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(0, 1, 0);
-    if constexpr (SCHED == 0) {
-        stage(1, 0, 1); stage(1, 3, 1); stage(1, 1, 1);           // A_0, B_1, A_1 of tile 1
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        stage(1, 0, 1); stage(1, 3, 1);                            // A_0, B_1 of tile 1
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3
-    for (int kt = 0; kt < nk; kt += 2) {
-        tile_phases(kt, I0{});
-        if (kt + 1 < nk) tile_phases(kt + 1, I1{});
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing empty loads have written their zeros
-    __syncthreads();                                    // all fragment reads done: the buffers become the epilogue slabs
-#undef P8_SYNC_MMA
-
-    // ---- epilogue.  C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r.  Wave patch: rows m0 + wr*128 .. +128,
-    // columns n0 + wc*64 .. +64; slab s = m-fragments 2s, 2s+1 (32 rows) x 64 columns, private to the wave.
-    float* slab = reinterpret_cast<float*>(smem + wave * SLAB_BYTES);
+    // ---- epilogue geometry.  C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r.  Wave patch: rows m0 + wr*128 ..
+    // +128, columns n0 + wc*64 .. +64; slab = one m-fragment (16 rows) x 64 columns, private to the wave: 4 KiB.
+    float* slab = reinterpret_cast<float*>(smem + (PERSIST ? 2 * BUF_BYTES : 0) + wave * SLAB_BYTES);
     const int e_c8 = lane & 7, e_r8 = lane >> 3;         // read-out: 8 lanes cover a slab row (64 columns), 8 rows per pass
-    const int e_n = n0 + wc * 64 + e_c8 * 8;
-    const int e_cnt = min(8, p.N - e_n);
-    const bool fast = (EPI == 0 || EPI == 1) && p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && !p.Cpre && !p.gelu_grad_of && !p.ln64_g;
-    float bias8[8];
+    auto epilogue = [&](int m0_, int n0_) {
+        const int e_n = n0_ + wc * 64 + e_c8 * 8;
+        const int e_cnt = min(8, p.N - e_n);
+        const bool fast = (EPI == 0 || EPI == 1) && p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && !p.Cpre && !p.gelu_grad_of && !p.ln64_g;
+        float bias8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if (fast && p.bias) {
-        const float* bsrc = p.bias + (long long)z * p.sBias + e_n;
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(bsrc), t1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
+        for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+        if (fast && p.bias) {
+            const float* bsrc = p.bias + (long long)z * p.sBias + e_n;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(bsrc), t1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { bias8[e] = t0[e]; bias8[4 + e] = t1[e]; }
-    }
-    const float* res32 = (fast && p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
-    const bf16_t* res16 = (fast && p.res && p.res_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes : nullptr;
-    float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
-    bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
-    auto slab_out = [&](auto sc) {                       // compile-time slab index: a run-time one would push the accumulators to scratch
-        constexpr int s = decltype(sc)::value;
-        const int mrow0 = m0 + wr * 128 + s * 32;
-        float aux[4][8];
-        if (fast) {                                      // residual rows requested before the slab is written
+            for (int e = 0; e < 4; ++e) { bias8[e] = t0[e]; bias8[4 + e] = t1[e]; }
+        }
+        const float* res32 = (fast && p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
+        const bf16_t* res16 = (fast && p.res && p.res_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes : nullptr;
+        float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
+        bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
+        auto slab_out = [&](auto ic) {                       // compile-time m-fragment index: a run-time one would push the accumulators to scratch
+            constexpr int i = decltype(ic)::value;
+            const int mrow0 = m0_ + wr * 128 + i * 16;
+            float aux[2][8];
+            if (fast) {                                      // residual rows requested before the slab is written
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) aux[u][e] = 0.f;
-                const int m = mrow0 + u * 8 + e_r8;
-                if (m < p.M) {
-                    if (res16) {
-                        const u32x4 tt = *reinterpret_cast<const u32x4*>(res16 + (long long)m * p.ldres + e_n);
+                    for (int e = 0; e < 8; ++e) aux[u][e] = 0.f;
+                    const int m = mrow0 + u * 8 + e_r8;
+                    if (m < p.M) {
+                        if (res16) {
+                            const u32x4 tt = *reinterpret_cast<const u32x4*>(res16 + (long long)m * p.ldres + e_n);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { aux[u][2 * e] = __uint_as_float(tt[e] << 16); aux[u][2 * e + 1] = __uint_as_float(tt[e] & 0xffff0000u); }
-                    } else if (res32) {
-                        const float* src = res32 + (long long)m * p.ldres + e_n;
-                        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+                            for (int e = 0; e < 4; ++e) { aux[u][2 * e] = __uint_as_float(tt[e] << 16); aux[u][2 * e + 1] = __uint_as_float(tt[e] & 0xffff0000u); }
+                        } else if (res32) {
+                            const float* src = res32 + (long long)m * p.ldres + e_n;
+                            const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { aux[u][e] = t0[e]; aux[u][4 + e] = t1[e]; }
+                            for (int e = 0; e < 4; ++e) { aux[u][e] = t0[e]; aux[u][4 + e] = t1[e]; }
+                        }
                     }
                 }
             }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(h * 16 + f_kg * 4 + r) * 64 + j * 16 + f_r] = acc[2 * s + h][j][r];
-        // the slab is private to the wave: its own LDS writes are ordered before its reads (lgkmcnt), no barrier
+                for (int r = 0; r < 4; ++r) slab[(f_kg * 4 + r) * 64 + j * 16 + f_r] = acc[i][j][r];
+            // the slab is private to the wave: its own LDS writes are ordered before its reads (lgkmcnt), no barrier
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = u * 8 + e_r8;
-            const int m = mrow0 + row;
-            if (m >= p.M || e_cnt <= 0) continue;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8 + 4);
-            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            if (!fast) {
-                epi_apply<EPI, true>(p, z, m, e_n, v, e_cnt, p.vec_epi != 0 && e_cnt == 8);
-                continue;
+            for (int u = 0; u < 2; ++u) {
+                const int row = u * 8 + e_r8;
+                const int m = mrow0 + row;
+                if (m >= p.M || e_cnt <= 0 || (dbg & 1)) continue;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8 + 4);
+                float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                if (!fast) {
+                    epi_apply<EPI, true>(p, z, m, e_n, v, e_cnt, p.vec_epi != 0 && e_cnt == 8);
+                    continue;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (p.alpha * v[e] + bias8[e]) + aux[u][e];
+                if ((EPI & 1) && p.act == SQ_ACT_GELU) {                     // same erf form as epi_apply<EPI, true>
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = sq_gelu<true>(v[e]);
+                } else if (p.act == SQ_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (c32) {
+                    float* d = c32 + (long long)m * p.ldc + e_n;
+                    *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+                const u32x4 packed = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                if (c16p) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = packed;
+                if (p.C2) *reinterpret_cast<u32x4*>(p.C2 + (long long)z * p.sC2 + (long long)m * p.ldc2 + e_n) = packed;   // bf16 operand copy
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (p.alpha * v[e] + bias8[e]) + aux[u][e];
-            if ((EPI & 1) && p.act == SQ_ACT_GELU) {                     // same erf form as epi_apply<EPI, true>
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = sq_gelu<true>(v[e]);
-            } else if (p.act == SQ_ACT_RELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (c32) {
-                float* d = c32 + (long long)m * p.ldc + e_n;
-                *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            }
-            const u32x4 packed = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-            if (c16p) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = packed;
-            if (p.C2) *reinterpret_cast<u32x4*>(p.C2 + (long long)z * p.sC2 + (long long)m * p.ldc2 + e_n) = packed;   // bf16 operand copy
-        }
+        };
+        slab_out(std::integral_constant<int, 0>{}); slab_out(std::integral_constant<int, 1>{});
+        slab_out(std::integral_constant<int, 2>{}); slab_out(std::integral_constant<int, 3>{});
+        slab_out(std::integral_constant<int, 4>{}); slab_out(std::integral_constant<int, 5>{});
+        slab_out(std::integral_constant<int, 6>{}); slab_out(std::integral_constant<int, 7>{});
     };
-    slab_out(std::integral_constant<int, 0>{});
-    slab_out(std::integral_constant<int, 1>{});
-    slab_out(std::integral_constant<int, 2>{});
-    slab_out(std::integral_constant<int, 3>{});
+
+    stage_first();
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // K-tile 0 has landed (persistent form: and the previous tile's stores are out)
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3
+        in_loop = true;
+        for (int kt = 0; kt < nk; kt += 2) {
+            tile_phases(kt, I0{});
+            if (kt + 1 < nk) tile_phases(kt + 1, I1{});
+        }
+        in_loop = false;
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing empty loads have written their zeros
+        __syncthreads();                                    // all fragment reads done: the buffers are free
+        if constexpr (!PERSIST) {
+            epilogue(m0, n0);
+            break;
+        } else {
+            idx += G;
+            const int t_next = idx < run_count(xcd) ? run_start(xcd) + idx : -1;
+            int m0n = 0, n0n = 0;
+            if (t_next >= 0) {                              // the next tile's first operands are requested BEFORE this tile's results are written
+                tile_coords(t_next, m0n, n0n);
+                set_src(m0n, n0n);
+                stage_first();
+            }
+            epilogue(m0, n0);
+            if (t_next < 0) break;
+            m0 = m0n; n0 = n0n;
+        }
+    }
+#undef P8_SYNC_MMA
 }
 
 }  // namespace
@@ -314,26 +373,54 @@ bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype) {
     return a.K % 8 == 0 && a.K >= min_k && a.N % BN == 0 && tiles >= min_tiles;
 }
 
-int g_p8_sched = -1;               // sq_dbg_set key 10 (probes): 0 / 1, -1 = environment (SQ_GEMM_P8_SCHED) or the default
+int g_p8_group_m = -1;             // sq_dbg_set key 11: tile rows per group of the tile walk (-1 = environment SQ_GEMM_P8_GROUP_M or 8)
+int g_p8_sched = -1;               // sq_dbg_set key 10 (probes): 0 = one block per tile, 1 = persistent blocks; -1 = environment (SQ_GEMM_P8_PERSIST) or 1
+int g_p8_skew = -1;                // sq_dbg_set key 12: start-up skew of the persistent form in cycles per step (-1 = environment SQ_GEMM_P8_SKEW or the default)
 namespace {
-template <int EPI, int SCHED>
+template <int EPI, bool PERSIST, bool DBG>
 int launch_p8(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+    constexpr int lds = PERSIST ? LDS_BYTES + 8 * SLAB_BYTES : LDS_BYTES;
     static SqDevOnce attr;       // hipFuncSetAttribute is per device
     if (attr.needed()) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_p8_kernel<EPI, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_p8_kernel<EPI, PERSIST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr.done();
     }
-    hipLaunchKernelGGL((gemm_p8_kernel<EPI, SCHED>), grid, dim3(NT), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_p8_kernel<EPI, PERSIST, DBG>), grid, dim3(NT), lds, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
+template <bool PERSIST>
+int launch_p8_pick(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.dbg) return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, true>(a, grid, stream) : launch_p8<0, PERSIST, true>(a, grid, stream);
+    return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, false>(a, grid, stream) : launch_p8<0, PERSIST, false>(a, grid, stream);
+}
+int p8_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (!cus[dev & 63]) {
+        hipDeviceProp_t prop;
+        cus[dev & 63] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev & 63];
+}
 }  // namespace
 
-int sq_launch_gemm_p8(const GemmArgs& a, hipStream_t stream) {
+int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    static int env_gm = -1, env_persist = -1, env_skew = -2;
+    if (env_gm < 0) { const char* e = getenv("SQ_GEMM_P8_GROUP_M"); env_gm = e ? atoi(e) : 8; }
+    if (env_persist < 0) { const char* e = getenv("SQ_GEMM_P8_PERSIST"); env_persist = e ? atoi(e) : 1; }
+    if (env_skew == -2) { const char* e = getenv("SQ_GEMM_P8_SKEW"); env_skew = e ? atoi(e) : -1; }
+    a.tile_group_m = g_p8_group_m > 0 ? g_p8_group_m : env_gm;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    const dim3 grid(tiles, 1, a.batch);
-    static int env_sched = -1;
-    if (env_sched < 0) { const char* e = getenv("SQ_GEMM_P8_SCHED"); env_sched = e ? atoi(e) : 1; }
-    if ((g_p8_sched >= 0 ? g_p8_sched : env_sched) == 0) return a.act == SQ_ACT_GELU ? launch_p8<1, 0>(a, grid, stream) : launch_p8<0, 0>(a, grid, stream);
-    return a.act == SQ_ACT_GELU ? launch_p8<1, 1>(a, grid, stream) : launch_p8<0, 1>(a, grid, stream);
+    const bool persist = (g_p8_sched >= 0 ? g_p8_sched : env_persist) != 0 && a.batch == 1;
+    const int cus = p8_cus() & ~7;
+    if (persist && tiles > cus && cus >= 8) {
+        // start-up skew (experiment knob, default none): measured SLOWER by more than the delay itself (50432 x 4096 x 1024: 454 us
+        // in step, 527 us with a quarter-tile skew) -- blocks of an XCD that drift apart stop sharing operand panels in L2
+        a.skew_cycles = g_p8_skew >= 0 ? g_p8_skew : env_skew >= 0 ? env_skew : 0;
+        return launch_p8_pick<true>(a, dim3(cus, 1, 1), stream);
+    }
+    return launch_p8_pick<false>(a, dim3(tiles, 1, a.batch), stream);
 }

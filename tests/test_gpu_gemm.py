@@ -192,14 +192,15 @@ def test_four_stage_256_tile_variant_matches_default_tile(M, N, K, act, waves):
 
 
 @pytest.mark.parametrize("M,N,K,act,out", [(256 * 9 + 37, 512, 320, 2, "bf16"), (700, 256 + 64, 1024, 1, "bf16"), (3000, 768, 72, 0, "f32"),
-                                           (256 * 40, 1024, 4096, 0, "f32")])
+                                           (256 * 40, 1024, 4096, 0, "f32"), (256 * 70 + 37, 1024, 320, 2, "bf16"), (256 * 33, 2048, 1088, 1, "f32")])
 @pytest.mark.parametrize("sched", [0, 1])
 def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched):
     """gemm_p8.hip (256 x 256 x 64 tile, two buffers of four half-tiles, eight phases per pair of K-tiles, the two wave rows one
     barrier apart, 16x16x32 MFMAs), forced through the experiment knob: ragged M / N / K (an odd number of K-tiles, a K-tile
     with a single 16-byte chunk), bias, bf16 residual, ReLU / GELU, bf16 / fp32 output against the fp32 product of the same
     bf16 operands and against the default tile (another MFMA shape sums K in another order: close, not bit-equal); run
-    three times -- a schedule race would show as run-to-run differences."""
+    three times -- a schedule race would show as run-to-run differences.  Persistent form (one block per CU walking its tiles, the
+    next tile's operands requested before the current tile's results are stored): the cases with more than 256 tiles."""
     _lib.require_gpu()
     lib = _lib.lib()
     lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -210,7 +211,7 @@ def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched):
     res = torch.randn(M, N, generator=g).cuda().bfloat16()
     odt, ocode = (torch.bfloat16, _lib.SQ_BF16) if out == "bf16" else (torch.float32, _lib.SQ_F32)
     outs = []
-    lib.sq_dbg_set(10, sched)            # 0: slots refilled one phase after their last read, fragment waits in front of the barrier; 1: two phases, behind it
+    lib.sq_dbg_set(10, sched)            # 0: one block per tile; 1: persistent blocks (when there are more tiles than CUs: the last two cases)
     try:
         for tile in (22, 88, 88, 88):
             lib.sq_dbg_set(0, tile)

@@ -70,6 +70,30 @@ if __name__ == "__main__":
         for M, N, K in [(50432, 4096, 1024), (50432, 3072, 1024)]:           # bf16 output (what the UNI blocks write)
             probe(M, N, K, _lib.SQ_BF16, tiles=(55, 88), dbgs=(0,), out_bf16=True, scheds=(0, 1))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8p":
+        # persistent form of gemm_p8.hip (sched 1) against one block per tile (sched 0), and its start-up skew (cycles per step; 0 = none)
+        for out_bf16 in (False, True):
+            for M, N, K in [(50432, 4096, 1024), (50432, 1024, 4096), (50432, 3072, 1024), (50432, 1024, 1024), (102400, 1024, 1024), (102400, 2048, 2048), (8192, 8192, 8192)]:
+                for skew in (-1, 0, 6000, 24000, -1):
+                    lib.sq_dbg_set(12, skew)
+                    print("skew", skew, "bf16 out" if out_bf16 else "fp32 out")
+                    probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0,), scheds=(0, 1) if skew == -1 else (1,), out_bf16=out_bf16)
+        lib.sq_dbg_set(12, -1)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8g":
+        # tile-walk group height of gemm_p8.hip (1 = row-major inside an XCD's run)
+        for M, N, K in [(8192, 8192, 8192), (50432, 4096, 1024), (50432, 1024, 4096), (50432, 3072, 1024), (102400, 2048, 2048), (102400, 1024, 1024)]:
+            for gm in (1, 2, 4, 8, 1, 4):
+                lib.sq_dbg_set(11, gm)
+                print("group_m", gm)
+                probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0,), scheds=(1,), out_bf16=True)
+        lib.sq_dbg_set(11, -1)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8a":
+        # ablation of gemm_p8.hip: 1 no stores, 2 no LDS-DMA in the loop, 4 no MFMA, 8 no fragment reads
+        for M, N, K in [(8192, 8192, 8192), (50432, 4096, 1024)]:
+            probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0, 1, 2, 4, 8, 6, 12, 10, 14, 0), scheds=(1,))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "w4":
         for M, N, K in [(8192, 8192, 8192), (4096, 4096, 4096), (102400, 1024, 1024), (50432, 4096, 1024), (50432, 1024, 4096), (24500, 512, 4608),
                         (24500, 2048, 1024), (98000, 1024, 512), (98000, 512, 1024), (6400, 1024, 1024)]:
