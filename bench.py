@@ -448,7 +448,10 @@ def workload_train_kfold(args, rank, world, device):
         if dump and rank == 0:
             torch.save(flat.cpu(), dump)
         return {"folds_run": state["folds_run"], "ranks_hold_identical_parameters": same,
-                "param_sum": float(sums[0]), "param_abs_sum": float(sums[1])}
+                "param_sum": float(sums[0]), "param_abs_sum": float(sums[1]),
+                # per training step of the last epoch (rank 0): backward pass, bucketed all-reduce busy time on the communication
+                # stream, and the part of it that stuck out behind the backward pass -- None on one rank
+                "gradient_exchange_ms_per_step": getattr(model, "last_exchange_timing", None)}
 
     def cpu_baseline():
         from oracle import vis_oracle
@@ -659,6 +662,12 @@ def main():
     if args.dtype in ("bf16x3", "f16x3") and not (args.workload == "pipeline" and args.embedder == "resnet"):
         raise SystemExit(f"--dtype {args.dtype} is the split mode of the ResNet-50 embedder (pipeline workload)")
 
+    share = os.environ.get("SQ_BENCH_SHARE_GPU") == "1"
+    if args.gpus > 1 and not share:
+        have = torch.cuda.device_count()
+        if have < args.gpus:          # said here, once, instead of N ranks fighting over cuda:0 or hanging in the RCCL rendezvous
+            raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this box has {have} "
+                             f"(one rank per GPU over RCCL; SQ_BENCH_SHARE_GPU=1 runs the ranks on cuda:0 over gloo to exercise the control flow only)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
     rank, world, local = dist_env()
@@ -668,9 +677,10 @@ def main():
     _lib.require_gpu()
     # SQ_BENCH_SHARE_GPU=1 (debugging aid for 1-GPU boxes): every rank uses cuda:0 and the collectives go through
     # gloo -- exercises the multi-process control flow (rendezvous, bucketed all-reduce, barriers), not RCCL
-    share = os.environ.get("SQ_BENCH_SHARE_GPU") == "1"
     device = torch.device("cuda", 0 if share else local)
     torch.cuda.set_device(device)
+    from sequoia_pub_amd.cli.common import bind_to_gpu_numa_node
+    numa = bind_to_gpu_numa_node(device.index)          # host thread + later pinned allocations next to this rank's GPU
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share:
@@ -688,6 +698,7 @@ def main():
             "warmup": res["warmup"], "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": res["config"],
             "roofline": res.get("roofline"), "cpu_baseline": res.get("cpu_baseline"), "timed_region_s": res["timed_region_s"],
+            "host_numa_binding": numa,
             "ranks": torch.distributed.get_world_size() if world > 1 else 1,
             "backend": (torch.distributed.get_backend() if world > 1 else None)}
     if "check" in res:

@@ -12,6 +12,48 @@ def seed_everything(seed):
     random.seed(seed)
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa_node(device_index):
+    """Pin this process's host threads to the CPUs of the NUMA node its GPU hangs off (PCI address -> sysfs numa_node ->
+    node cpulist -> sched_setaffinity).  On an 8-GPU node every rank then drives its GPU, and first-touches its pinned
+    staging buffers, from the local socket instead of wherever the launcher started it.  Never fails: returns a dict that
+    says what was done (bench.py prints it), or why nothing was."""
+    info = {"gpu": int(device_index), "node": None, "cpus": None, "bound": False}
+    try:
+        import torch
+        prop = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+        info["pci"] = bdf
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        info["node"] = node
+        if node < 0:
+            info["why"] = "the platform reports no NUMA affinity for this device (single node or virtualised)"
+            return info
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = _parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        if not cpus:
+            info["why"] = "none of the node's CPUs is in this process's allowed set"
+            return info
+        os.sched_setaffinity(0, cpus)
+        info["cpus"] = len(cpus)
+        info["bound"] = True
+    except Exception as e:                      # sysfs layout, permissions, attribute names: never worth failing a run for
+        info["why"] = f"{type(e).__name__}: {e}"
+    return info
+
+
 def init_distributed():
     """Returns (rank, world, device).  Under torchrun each rank owns LOCAL_RANK's GPU and the default
     process group is RCCL ('nccl' backend on ROCm); otherwise single GPU cuda:0."""
@@ -21,6 +63,8 @@ def init_distributed():
     device = torch.device("cuda", local)
     if torch.cuda.is_available():
         torch.cuda.set_device(device)
+        if world > 1:
+            bind_to_gpu_numa_node(local)
     if world > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl" if torch.cuda.is_available() else "gloo")

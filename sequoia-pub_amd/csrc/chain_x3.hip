@@ -94,7 +94,7 @@ struct ChainX3Args {
     int dbg;                                     // ablation switches (tools/chain_probe.py): 1 no stores, 2 no identity reads, 4 no 3x3, 8 no second product
 };
 
-template <int N2, bool F16, bool DS, bool TAIL>
+template <int N2, bool F16, bool DS, bool TAIL, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     using Fmt = X3Fmt<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -172,9 +172,14 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         // ---- 0. t2 = relu(conv3x3(t1) * s2 + b2) for this tile, never leaving the CU.  The tile's 64 flat pixels need the
         // contiguous rows [p0 - W - 1, p0 + 64 + W + 1) of t1 (<= 192 rows, W <= 62): both 32-channel blocks and both planes
         // arrive at once (48 KiB); the weights stream as 18 tiles [64 n][32 k] x 2 planes through a four-stage ring (32 KiB).
+        // WIDE (maps 63 .. 70 wide -- the 64 x 64 maps of 256-pixel patches, the reference's default size,
+        // pre_processing/patch_gen_hdf5.py:157): <= 206 rows in 208-row planes (52 KiB) and a THREE-stage ring (24 KiB), so
+        // that the block still fits 80 KiB and two of them a CU.
         // 4 waves = 2 (32 pixels) x 2 (32 channels), 6 MFMAs per wave and step -- the same K order (channel block, tap) and
         // MFMA sequence as conv_halo_x3.hip.  The result goes to LDS as the A image of the first product.
-        constexpr int HROWS = 192, HPL = HROWS * 64, HCB = 2 * HPL, WST = 8192;
+        constexpr int HROWS = WIDE ? 208 : 192, HPL = HROWS * 64, HCB = 2 * HPL, WST = 8192;
+        constexpr int NST = WIDE ? 3 : 4, DEPTH = NST - 1, NROUND = (HROWS + 63) / 64;
+        static_assert(2 * HCB + NST * WST <= LDS_BYTES, "tail form: input rows + weight ring exceed the block's LDS");
         char* const HB = smem;
         char* const WR = smem + 2 * HCB;
         const int W = p.W;
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < NROUND; ++u) {
+                    if (u * 64 + wave * 16 >= HROWS) continue;          // (wave-uniform) the last round of the 208-row planes: one chunk of 16 rows
                     const int sl = u * 256 + tid;
                     const int row = sl >> 2, c = (sl & 3) ^ ((row >> 2) & 3);
                     const int px = halo0 + row;
@@ -205,9 +211,8 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             glds16(rs2h, dst, off);
             glds16(rs2l, dst + 4096, off);
         };
-        issue_w2(0, 0);
-        issue_w2(1, 1);
-        issue_w2(2, 2);
+#pragma unroll
+        for (int g0 = 0; g0 < DEPTH; ++g0) issue_w2(g0, g0);
         asm volatile("" ::: "memory");
         const int pi3 = wave >> 1, cj3 = wave & 1;
         const int ml = pi3 * 32 + l31;
@@ -234,14 +239,14 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int g = cb * 9 + tap;
-                // tile g (and everything older) landed.  Requested after it, in this order: extra group g-3 (4 reads),
+                // tile g (and everything older) landed.  Requested after it, in this order (DEPTH = 3): extra group g-3 (4 reads),
                 // tile g+1 (2), extra g-2, tile g+2, extra g-1 -- those that exist may stay in flight
                 {
                     int n = 0;
 #pragma unroll
-                    for (int k = g - 3; k < g; ++k) n += (k >= 0 && k < NEXTRA) ? 4 : 0;
+                    for (int k = g - DEPTH; k < g; ++k) n += (k >= 0 && k < NEXTRA) ? 4 : 0;
 #pragma unroll
-                    for (int j = g + 1; j <= g + 2; ++j) n += j < 18 ? 2 : 0;
+                    for (int j = g + 1; j <= g + DEPTH - 1; ++j) n += j < 18 ? 2 : 0;
                     wait_vm_n(n);
                 }
                 __builtin_amdgcn_s_barrier();
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                 const char* arow = HB + cb * HCB + j * 64;
                 const int asw = (j >> 2) & 3;
                 const bool aok = (mask >> tap) & 1u;
-                const char* wt = WR + (g & 3) * WST + brow * 64;
+                const char* wt = WR + (g % NST) * WST + brow * 64;
                 const int bsw = (brow >> 2) & 3;
                 u32x4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                     if (!aok) { ah[s2] = u32x4{0, 0, 0, 0}; al[s2] = u32x4{0, 0, 0, 0}; }
                     bh[s2] = lds128(wt + (((2 * s2 + lh) ^ bsw) << 4)); bl[s2] = lds128(wt + 4096 + (((2 * s2 + lh) ^ bsw) << 4));
                 }
-                if (g + 3 < 18) issue_w2(g + 3, (g + 3) & 3);           // into the stage read at step g - 1; behind the fragment reads, whose latency covers the DMA issue
+                if (g + DEPTH < 18) issue_w2(g + DEPTH, (g + DEPTH) % NST);     // into the stage read at step g - 1; behind the fragment reads, whose latency covers the DMA issue
                 asm volatile("" ::: "memory");           // (the counted waits above rely on this order)
                 if (g < NEXTRA) extra_reads(g);
                 asm volatile("" ::: "memory");
@@ -534,8 +539,9 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     SQ_REQUIRE(P > 0 && P * N1 * 2 < (1ll << 31), "chain_x3: %lld pixels exceed the 2 GiB descriptor limit", P);
     const bool tail = t1 != nullptr;
     SQ_REQUIRE((t2 || tail) && y && t1n && w3 && w1n && b3 && b1n && frag && w3_bytes >= (size_t)N1 * K1 * 2, "chain_x3: null pointer / weight extent");
-    SQ_REQUIRE(!tail || (w2 && b2 && w2_bytes >= (size_t)64 * 576 * 2 && W >= 3 && W <= 62 && HW == W * W && P % HW == 0),
-               "chain_x3: tail form needs the 3x3 weights and square maps up to 62 wide (W=%d)", W);
+    SQ_REQUIRE(!tail || (w2 && b2 && w2_bytes >= (size_t)64 * 576 * 2 && W >= 3 && W <= 70 && HW == W * W && P % HW == 0),
+               "chain_x3: tail form needs the 3x3 weights and square maps up to 70 wide (W=%d)", W);
+    const bool wide = tail && W > 62;             // 63 .. 70: 208-row planes, three-stage weight ring
     const bool ds = res == nullptr;
     SQ_REQUIRE(!ds || (xin && wd && bd && wd_bytes >= (size_t)N1 * K1 * 2), "chain_x3: neither an identity tensor nor a downsample branch");
     ChainX3Args a;
@@ -553,7 +559,8 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     using I64 = std::integral_constant<int, 64>; using I128 = std::integral_constant<int, 128>;
     using T = std::true_type; using F = std::false_type;
     auto pick_tail = [&](auto n2c, auto f16c, auto dsc) {
-        return tail ? (const void*)chain_x3_kernel<decltype(n2c)::value, decltype(f16c)::value, decltype(dsc)::value, true>
+        return wide ? (const void*)chain_x3_kernel<decltype(n2c)::value, decltype(f16c)::value, decltype(dsc)::value, true, true>
+             : tail ? (const void*)chain_x3_kernel<decltype(n2c)::value, decltype(f16c)::value, decltype(dsc)::value, true>
                     : (const void*)chain_x3_kernel<decltype(n2c)::value, decltype(f16c)::value, decltype(dsc)::value, false>;
     };
     auto pick_ds = [&](auto n2c, auto f16c) { return ds ? pick_tail(n2c, f16c, T{}) : pick_tail(n2c, f16c, F{}); };

@@ -235,7 +235,18 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     auto epilogue = [&](int m0_, int n0_) {
         const int e_n = n0_ + wc * 64 + e_c8 * 8;
         const int e_cnt = min(8, p.N - e_n);
-        const bool fast = (EPI == 0 || EPI == 1) && p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && !p.Cpre && !p.gelu_grad_of && !p.ln64_g;
+        const bool fast = p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && !p.Cpre && !p.gelu_grad_of && ((EPI & 4) != 0) == (p.ln64_g != nullptr);
+        // EPI & 4: per-head LayerNorm(64) + affine between the bias / residual and the activation (src/tformer_lin.py:20-21: the f
+        // projection's local_norm): a slab row IS one head -- the wave's 64 columns -- and lives in 8 consecutive lanes
+        float lng[8], lnb[8];
+        if constexpr ((EPI & 4) != 0) {
+            if (fast) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln64_g + e_n), g1 = *reinterpret_cast<const f32x4*>(p.ln64_g + e_n + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln64_b + e_n), b1 = *reinterpret_cast<const f32x4*>(p.ln64_b + e_n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lng[e] = g0[e]; lng[4 + e] = g1[e]; lnb[e] = b0[e]; lnb[4 + e] = b1[e]; }
+            }
+        }
         float bias8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -292,6 +303,18 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (p.alpha * v[e] + bias8[e]) + aux[u][e];
+                if constexpr ((EPI & 4) != 0) {          // two-pass mean / variance as nn.LayerNorm, eps 1e-5 (the arithmetic of gemm.hip's epilogue)
+                    float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                    const float mean = sm * (1.0f / 64.0f);
+                    float q = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+                    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                    const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * lng[e] + lnb[e];
+                }
                 if ((EPI & 1) && p.act == SQ_ACT_GELU) {                     // same erf form as epi_apply<EPI, true>
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = sq_gelu<true>(v[e]);
@@ -358,7 +381,8 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
 // true when the eight-phase 256 x 256 x 64 kernel takes the product: bf16, plain (no convolution view), K in whole 16-byte
 // chunks, enough tiles to give (nearly) every CU one, and only the epilogues its prefetching fast path covers
 bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype) {
-    if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.ln64_g || a.rowbias || a.Cpre || a.gelu_grad_of || !a.vec_epi) return false;
+    if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.rowbias || a.Cpre || a.gelu_grad_of || !a.vec_epi) return false;
+    if (a.ln64_g && (a.N % 64 || !a.ln64_b)) return false;
     static int on = -1, min_tiles = 0, min_k = 0;
     if (on < 0) {
         const char* e = getenv("SQ_GEMM_P8");
@@ -392,6 +416,7 @@ int launch_p8(const GemmArgs& a, dim3 grid, hipStream_t stream) {
 template <bool PERSIST>
 int launch_p8_pick(const GemmArgs& a, dim3 grid, hipStream_t stream) {
     if (a.dbg) return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, true>(a, grid, stream) : launch_p8<0, PERSIST, true>(a, grid, stream);
+    if (a.ln64_g) return launch_p8<5, PERSIST, false>(a, grid, stream);          // LayerNorm(64) [+ GELU when act says so]
     return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, false>(a, grid, stream) : launch_p8<0, PERSIST, false>(a, grid, stream);
 }
 int p8_cus() {
@@ -408,6 +433,7 @@ int p8_cus() {
 
 int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
+    SQ_REQUIRE(!a.ln64_g || (a.ln64_b && a.N % BN == 0 && a.vec_epi), "gemm_p8: the LayerNorm(64) epilogue needs N %% 256 == 0 and 16-byte aligned epilogue operands");
     static int env_gm = -1, env_persist = -1, env_skew = -2;
     if (env_gm < 0) { const char* e = getenv("SQ_GEMM_P8_GROUP_M"); env_gm = e ? atoi(e) : 8; }
     if (env_persist < 0) { const char* e = getenv("SQ_GEMM_P8_PERSIST"); env_persist = e ? atoi(e) : 1; }

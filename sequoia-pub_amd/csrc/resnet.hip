@@ -389,7 +389,7 @@ extern "C" int sq_resnet50_extract_checked(int dtype, const void* weights, const
                 cnext < SQ_RESNET50_CONVS && lay.conv[cnext].k == 1 && lay.conv[cnext].stride == 1 && lay.conv[cnext].cin == 256 &&
                 (lay.conv[cnext].cout == 64 || lay.conv[cnext].cout == 128) &&
                 (!has_ds || (lay.conv[ci + 3].k == 1 && lay.conv[ci + 3].stride == 1 && lay.conv[ci + 3].cin == 64 && !sq_env_flag("SQ_RESNET_NO_CHAIN_DS")));
-            const bool x3_tail = x3_chain && c2.k == 3 && c2.cin == 64 && c2.cout == 64 && H <= 62 && !sq_env_flag("SQ_RESNET_NO_TAIL");
+            const bool x3_tail = x3_chain && c2.k == 3 && c2.cin == 64 && c2.cout == 64 && H <= 70 && !sq_env_flag("SQ_RESNET_NO_TAIL");
             if (!x3_tail) RUN(conv(c2, t1, H, t2, OH, nullptr, SQ_ACT_RELU));
             if (x3_chain) {
                 const sq_conv_desc& n1 = lay.conv[cnext];

@@ -145,6 +145,10 @@ class FusedTrainStep:
             with torch.cuda.device(dev):
                 for e in self.events:
                     e.record()              # instantiates the hipEvent_t the C side records into
+        # exchange-step timing (every 16th step, read back one sample later so that nothing waits): how long the backward
+        # pass ran, how long the bucketed all-reduce was busy behind it, and how much of it stuck out past the backward
+        # pass -- what a first multi-GPU run needs to explain its own scaling (timing_report(); train() prints it per epoch)
+        self._tm = dict(n=0, backward_ms=0.0, allreduce_span_ms=0.0, exposed_ms=0.0, pending=None)
 
     def step(self, x, target, n_global=None):
         """One optimizer step.  x [B, 100, D], target [B, G].  n_global: number of target elements of this step over
@@ -175,13 +179,25 @@ class FusedTrainStep:
                 for e in self.events:
                     e.record(main)
             else:
+                sample = self.step_count % 16 == 0
+                if sample:
+                    self._collect_timing()
+                    tb0, tb1, tc0, tc1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+                    tb0.record(main)
                 gflat, _ = vis_backward(m, gpred, B, False, bucket_events=self.events)
+                if sample:
+                    tb1.record(main)
             reduce_ = dist.is_available() and dist.is_initialized()
-            for (lo, hi), ev in zip(self.buckets, self.events):
+            for i, ((lo, hi), ev) in enumerate(zip(self.buckets, self.events)):
                 self.comm_stream.wait_event(ev)
+                if not empty and sample and i == 0:
+                    tc0.record(self.comm_stream)
                 if reduce_:
                     with torch.cuda.stream(self.comm_stream):
                         dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
+            if not empty and sample:
+                tc1.record(self.comm_stream)
+                self._tm["pending"] = (tb0, tb1, tc0, tc1)
             main.wait_stream(self.comm_stream)
         self.step_count += 1
         lp = m._params_lp()
@@ -192,6 +208,35 @@ class FusedTrainStep:
                                                 _lib.stream_ptr(dev)))
         # the kernel refreshed the bf16 shadow in the same pass (flat._version is unchanged by C-side writes)
         return None if empty else (loss, pred, mets)
+
+    def _collect_timing(self):
+        pend = self._tm.get("pending") if hasattr(self, "_tm") else None
+        if pend is None:
+            return
+        tb0, tb1, tc0, tc1 = pend
+        tc1.synchronize()                         # a sample from >= 16 steps ago: long complete
+        tb1.synchronize()
+        self._tm["pending"] = None
+        self._tm["n"] += 1
+        self._tm["backward_ms"] += tb0.elapsed_time(tb1)
+        self._tm["allreduce_span_ms"] += tc0.elapsed_time(tc1)
+        self._tm["exposed_ms"] += max(0.0, tb1.elapsed_time(tc1))
+
+    def timing_report(self, reset=True):
+        """Mean over the sampled steps since the last report: backward pass, first-bucket-ready -> last all-reduce done on the
+        communication stream, and the part of that span behind the end of the backward pass (the exposed exchange time).
+        None when the exchange path is off (one rank) or nothing was sampled."""
+        if not self.overlap:
+            return None
+        self._collect_timing()
+        n = self._tm["n"]
+        if n == 0:
+            return None
+        out = {k: round(self._tm[k] / n, 4) for k in ("backward_ms", "allreduce_span_ms", "exposed_ms")}
+        out["sampled_steps"] = n
+        if reset:
+            self._tm.update(n=0, backward_ms=0.0, allreduce_span_ms=0.0, exposed_ms=0.0)
+        return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -356,6 +401,13 @@ def train(model, dataloaders, optimizer=None, accelerator=None,
                 run.log({'epoch': epoch, f'{phase}{tag} mae fold {split}': A})
             if verbose and rank == 0:
                 print(f'Epoch {epoch}: {phase} loss {L} mae {A}')
+            if training and fused is not None and world > 1:
+                tr = fused.timing_report()
+                model.last_exchange_timing = tr                    # bench.py train_kfold prints it in its `check` block
+                if tr is not None and verbose and rank == 0:
+                    print(f"Epoch {epoch}: gradient exchange per step -- backward {tr['backward_ms']:.3f} ms, bucketed all-reduce busy "
+                          f"{tr['allreduce_span_ms']:.3f} ms, of which {tr['exposed_ms']:.3f} ms behind the end of the backward pass "
+                          f"({tr['sampled_steps']} sampled steps, {world} ranks)")
             if phase in observing:
                 for why in policy.observe(L, S):
                     if rank == 0 and save_path is not None:

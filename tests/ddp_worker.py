@@ -45,6 +45,8 @@ def main():
     torch.cuda.synchronize()
     g2 = m._gflat.clone()
     flat = m.flat.detach().clone()
+    tr = step.timing_report()                                   # step 1 was sampled: backward time, all-reduce span, exposed part
+    assert tr is not None and tr["sampled_steps"] == 1 and tr["backward_ms"] > 0 and tr["allreduce_span_ms"] > 0 and tr["exposed_ms"] >= 0, tr
 
     # every rank must hold the same parameters afterwards
     both = [torch.empty_like(flat) for _ in range(world)]

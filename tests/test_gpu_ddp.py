@@ -25,6 +25,20 @@ def test_two_rank_fused_step_equals_one_rank_step(tmp_path):
     assert ok.read_text() == "ok"
 
 
+def test_more_ranks_than_gpus_is_refused_not_hung():
+    """bench.py --gpus 2 on a box with one GPU (and without the shared-GPU debugging switch): a clear refusal within seconds,
+    not two ranks fighting over cuda:0 or a hang in the RCCL rendezvous."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the refusal path is for 1-GPU boxes")
+    env = {k: v for k, v in os.environ.items() if k != "SQ_BENCH_SHARE_GPU"}
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workload", "vis_fwd", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "needs 2 visible GPUs" in (r.stderr + r.stdout), (r.stdout[-500:], r.stderr[-1500:])
+
+
 def _bench_kfold(tmp_path, gpus, batch, tag):
     import json
     dump = tmp_path / f"params_{tag}.pt"
@@ -48,6 +62,8 @@ def test_config4_train_kfold_two_ranks_equal_one_rank_at_the_same_global_batch(t
     assert two["ranks"] == 2 and two["backend"] == "gloo" and two["n_gpus"] == 2 and one["ranks"] == 1
     assert two["check"]["folds_run"] == 5 and one["check"]["folds_run"] == 5
     assert two["check"]["ranks_hold_identical_parameters"] is True
+    ex = two["check"]["gradient_exchange_ms_per_step"]           # what a first multi-GPU run needs to explain its scaling
+    assert ex is not None and ex["backward_ms"] > 0 and ex["allreduce_span_ms"] > 0 and one["check"]["gradient_exchange_ms_per_step"] is None
     assert two["config"]["slides"] == 32 and one["config"]["slides"] == 32
     a, b = torch.load(p2), torch.load(p1)
     d = (a - b).abs()

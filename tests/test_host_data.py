@@ -144,3 +144,12 @@ def test_checkpoint_policy_equals_reference_trace(golden_dir):
                 break
         assert saves == c["save_epochs"], (c["kind"], c["save_on"], c["stop_on"], c["patience"])
         assert ran == c["epochs_run"], (c["kind"], c["save_on"], c["stop_on"], c["patience"])
+
+
+def test_numa_binding_helper_never_fails():
+    """cli/common.bind_to_gpu_numa_node: parses sysfs cpulists and reports instead of raising when there is no GPU / no sysfs
+    entry (this container); on an 8-GPU node it pins each rank's host threads next to its GPU."""
+    from sequoia_pub_amd.cli.common import _parse_cpulist, bind_to_gpu_numa_node
+    assert _parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and _parse_cpulist("") == set()
+    info = bind_to_gpu_numa_node(0)
+    assert info["gpu"] == 0 and isinstance(info["bound"], bool) and (info["bound"] or "why" in info)
