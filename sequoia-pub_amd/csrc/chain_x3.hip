@@ -205,8 +205,12 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                 }
         }
         const int wn_ = tid >> 2, wc_ = (tid & 3) ^ ((wn_ >> 2) & 3);
+        // step g of the K walk: (channel block, tap) = (g / 9, g % 9) -- conv_halo_x3.hip's order -- or, WIDE, (g & 1, g >> 1): the
+        // tap-major order of the implicit-GEMM kernel that takes these maps when the 3x3 runs on its own (conv_halo_x3.hip stops
+        // at 63 columns), so that either form stays bit-identical to its unfused path.  Weight tile of a step: cb * 9 + tap.
         auto issue_w2 = [&](int g, int stage) {
-            const uint32_t off = ((uint32_t)g * 2048u + (uint32_t)(wn_ * 32 + wc_ * 8)) * 2u;      // tile g = [64 n][32 k], contiguous
+            const int tile = WIDE ? (g & 1) * 9 + (g >> 1) : g;
+            const uint32_t off = ((uint32_t)tile * 2048u + (uint32_t)(wn_ * 32 + wc_ * 8)) * 2u;   // tile = [64 n][32 k], contiguous
             char* dst = WR + stage * WST + wave * 1024;
             glds16(rs2h, dst, off);
             glds16(rs2l, dst + 4096, off);
@@ -235,10 +239,8 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
         if (!(p.dbg & 4))
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int g = cb * 9 + tap;
+            for (int g = 0; g < 18; ++g) {
+                const int cb = WIDE ? (g & 1) : g / 9, tap = WIDE ? (g >> 1) : g % 9;
                 // tile g (and everything older) landed.  Requested after it, in this order (DEPTH = 3): extra group g-3 (4 reads),
                 // tile g+1 (2), extra g-2, tile g+2, extra g-1 -- those that exist may stay in flight
                 {
