@@ -97,6 +97,53 @@ __global__ __launch_bounds__(256) void uni_ln_kernel(const float* __restrict__ x
     }
 }
 
+// The same for D = 512 NI (ViT-L: D = 1024, NI = 2): a lane owns 8 consecutive columns per 512-column block -- two 16-byte loads,
+// one 16-byte bf16 store (or two fp32 ones), everything in registers with compile-time indices.  The generic kernel above indexes
+// v[] with a run-time trip count (scratch memory) and stores 2 bytes per lane: 190 us per [50432, 1024] call = 1.6 TB/s,
+// 19 % of the UNI forward (rocprofv3, round 4); this one streams the same rows at the fabric's rate.
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void uni_ln8_kernel(const float* __restrict__ x, size_t row_stride, const float* __restrict__ g,
+                                                      const float* __restrict__ b, T* __restrict__ y, int R, float eps) {
+    constexpr int D = 512 * NI;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* xr = x + (size_t)row * row_stride + lane * 8;
+    float v[NI][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(xr + i * 512), t1 = *reinterpret_cast<const f32x4*>(xr + i * 512 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = t0[e]; v[i][4 + e] = t1[e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+    const float mean = wave_sum(s) * (1.0f / (float)D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[i][e] -= mean; q += v[i][e] * v[i][e]; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / (float)D) + eps);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = i * 512 + lane * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + c), g1 = *reinterpret_cast<const f32x4*>(g + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + c), b1 = *reinterpret_cast<const f32x4*>(b + c + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = v[i][e] * rstd * g0[e] + b0[e]; o[4 + e] = v[i][4 + e] * rstd * g1[e] + b1[e]; }
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<u32x4*>(y + (size_t)row * D + c) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        } else {
+            float* d = reinterpret_cast<float*>(y) + (size_t)row * D + c;
+            *reinterpret_cast<f32x4*>(d) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(d + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+    }
+}
+
 // softmax(q k^T * scale) v for one (image, head): q / k / v rows of this head staged in LDS as fp32,
 // wave w owns query rows w, w+4, ...; lane = key (4 per lane) for the scores, lane = channel for P V
 template <typename T>
@@ -380,7 +427,10 @@ extern "C" int sq_uni_forward(const sq_uni_config* c, int dtype, const float* pa
     auto Bf = [&](int64_t off) { return bias_exec + off; };
     auto grid_for = [](size_t work) { size_t nb = (work + 255) / 256; return (int)(nb > 65535 ? 65535 : (nb ? nb : 1)); };
     auto ln = [&](const float* x, size_t stride, int64_t g, int64_t b, void* y, int ydt, int R) -> int {
-        if (ydt == SQ_BF16) hipLaunchKernelGGL(uni_ln_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, x, stride, Pf(g), Pf(b), (bf16_t*)y, R, D, 1e-6f);
+        const bool v8 = D == 1024 && stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)Pf(g) | (uintptr_t)Pf(b)) & 15) == 0 && !sq_env_flag("SQ_UNI_LN_GENERIC");
+        if (v8 && ydt == SQ_BF16) hipLaunchKernelGGL((uni_ln8_kernel<bf16_t, 2>), dim3((R + 3) / 4), dim3(256), 0, s, x, stride, Pf(g), Pf(b), (bf16_t*)y, R, 1e-6f);
+        else if (v8) hipLaunchKernelGGL((uni_ln8_kernel<float, 2>), dim3((R + 3) / 4), dim3(256), 0, s, x, stride, Pf(g), Pf(b), (float*)y, R, 1e-6f);
+        else if (ydt == SQ_BF16) hipLaunchKernelGGL(uni_ln_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, x, stride, Pf(g), Pf(b), (bf16_t*)y, R, D, 1e-6f);
         else hipLaunchKernelGGL(uni_ln_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, s, x, stride, Pf(g), Pf(b), (float*)y, R, D, 1e-6f);
         SQ_LAUNCH_CHECK();
         return SQ_OK;
