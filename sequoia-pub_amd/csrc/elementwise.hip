@@ -73,6 +73,108 @@ __global__ __launch_bounds__(256) void token_mean_kernel(const void* __restrict_
     }
 }
 
+// bf16 rows (the residual stream of bf16 inference), 16-byte loads: thread = (b, 8 columns, quarter of the tokens), five
+// independent loads in flight per thread.  Per column the additions happen in exactly the order of token_mean_kernel (a quarter's
+// tokens in sequence, the quarters as (q0 + q1) + (q2 + q3)): same bits.  The 8-byte / one-load-at-a-time form above ran
+// the spatial path's [102400, 1024] reduction at 1.2 TB/s (181 us, 11 % of a layer: rocprofv3, round 4).
+__global__ __launch_bounds__(256) void token_mean_bf16x8_kernel(const u32x4* __restrict__ X, float4* __restrict__ out, uint2* __restrict__ outh,
+                                                                int B, int N, int D8) {
+    __shared__ float red[4][64][8];
+    const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (i < B * D8) {
+        const int b = i / D8, d = i - b * D8;
+        const u32x4* p = X + (size_t)b * N * D8 + d;
+        const int per = (N + 3) / 4, lo = q * per, hi = min(N, lo + per);
+        int n = lo;
+        for (; n + 5 <= hi; n += 5) {
+            u32x4 t[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) t[u] = p[(size_t)(n + u) * D8];
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(t[u][e] << 16); acc[2 * e + 1] += __uint_as_float(t[u][e] & 0xffff0000u); }
+        }
+        for (; n < hi; ++n) {
+            const u32x4 t = p[(size_t)n * D8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(t[e] << 16); acc[2 * e + 1] += __uint_as_float(t[e] & 0xffff0000u); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[q][tx][e] = acc[e];
+    __syncthreads();
+    if (q == 0 && i < B * D8) {
+        const float inv = 1.0f / (float)N;
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = ((red[0][tx][e] + red[1][tx][e]) + (red[2][tx][e] + red[3][tx][e])) * inv;
+        out[2 * i] = make_float4(r[0], r[1], r[2], r[3]);
+        out[2 * i + 1] = make_float4(r[4], r[5], r[6], r[7]);
+        if (outh) {
+            outh[2 * i] = make_uint2(pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]));
+            outh[2 * i + 1] = make_uint2(pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7]));
+        }
+    }
+}
+
+// LayerNorm of bf16 rows with D = 512 NI, bf16 or fp32 out: a lane owns 8 consecutive columns per 512-column block (one 16-byte
+// load, one 16-byte bf16 store).  Statistics two-pass in fp32 like ln_rows_kernel; the order of the partial sums differs from
+// it (8 columns per lane instead of 4), i.e. results agree to fp32 rounding, not bitwise -- used for the bf16 stream only.
+template <int NI>
+__global__ __launch_bounds__(256) void ln_rows_bf16x8_kernel(const u32x4* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                             void* __restrict__ y, int out_bf16, int R, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out) {
+    constexpr int D = 512 * NI;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float v[NI][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const u32x4 t = x[(size_t)row * (D / 8) + i * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][2 * e] = __uint_as_float(t[e] << 16); v[i][2 * e + 1] = __uint_as_float(t[e] & 0xffff0000u); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float a = v[i][e] - mean; q += a * a; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + LN_EPS);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = i * 512 + lane * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(g + c), g1 = *reinterpret_cast<const float4*>(g + c + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+        float o[8];
+        o[0] = (v[i][0] - mean) * rstd * g0.x + b0.x; o[1] = (v[i][1] - mean) * rstd * g0.y + b0.y;
+        o[2] = (v[i][2] - mean) * rstd * g0.z + b0.z; o[3] = (v[i][3] - mean) * rstd * g0.w + b0.w;
+        o[4] = (v[i][4] - mean) * rstd * g1.x + b1.x; o[5] = (v[i][5] - mean) * rstd * g1.y + b1.y;
+        o[6] = (v[i][6] - mean) * rstd * g1.z + b1.z; o[7] = (v[i][7] - mean) * rstd * g1.w + b1.w;
+        if (out_bf16) {
+            reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(y) + (size_t)row * D)[i * 64 + lane] =
+                u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        } else {
+            float* d = reinterpret_cast<float*>(y) + (size_t)row * D + c;
+            *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+
 // one wave per row; row kept in registers between the mean and variance passes
 template <int MAXI, bool IN_BF16>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const void* __restrict__ x, const float* __restrict__ g,
@@ -264,7 +366,9 @@ int sq_k_token_mean(const float* X, float* out, bf16_t* outh, int B, int N, int 
 int sq_k_token_mean_any(const void* X, int in_dtype, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s) {
     SQ_REQUIRE(D % 4 == 0, "token_mean: D=%d must be a multiple of 4", D);
     const int total = B * (D / 4);
-    if (in_dtype == SQ_BF16)
+    if (in_dtype == SQ_BF16 && D % 8 == 0 && (((uintptr_t)X | (uintptr_t)out | (uintptr_t)outh) & 15) == 0 && !sq_env_flag("SQ_ELEMENTWISE_NARROW"))
+        hipLaunchKernelGGL(token_mean_bf16x8_kernel, dim3((B * (D / 8) + 63) / 64), dim3(256), 0, s, (const u32x4*)X, (float4*)out, (uint2*)outh, B, N, D / 8);
+    else if (in_dtype == SQ_BF16)
         hipLaunchKernelGGL(token_mean_kernel<true>, dim3((total + 63) / 64), dim3(256), 0, s, X, (float4*)out, (uint2*)outh, B, N, D / 4);
     else
         hipLaunchKernelGGL(token_mean_kernel<false>, dim3((total + 63) / 64), dim3(256), 0, s, X, (float4*)out, (uint2*)outh, B, N, D / 4);
@@ -282,7 +386,12 @@ int sq_k_ln_rows_any(const void* x, int in_dtype, const float* g, const float* b
     SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows: D=%d must be a multiple of 4 and <= 4096", D);
     const dim3 grid((R + 3) / 4), block(256);
     const int ob = out_dtype == SQ_BF16;
-    if (in_dtype == SQ_BF16) {
+    const bool wide = in_dtype == SQ_BF16 && (D == 1024 || D == 2048) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)g | (uintptr_t)b) & 15) == 0 &&
+        !sq_env_flag("SQ_ELEMENTWISE_NARROW");
+    if (wide) {
+        if (D == 1024) hipLaunchKernelGGL((ln_rows_bf16x8_kernel<2>), grid, block, 0, s, (const u32x4*)x, g, b, y, ob, R, mean_out, rstd_out);
+        else hipLaunchKernelGGL((ln_rows_bf16x8_kernel<4>), grid, block, 0, s, (const u32x4*)x, g, b, y, ob, R, mean_out, rstd_out);
+    } else if (in_dtype == SQ_BF16) {
         if (D <= 1024) hipLaunchKernelGGL((ln_rows_kernel<4, true>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
         else if (D <= 2048) hipLaunchKernelGGL((ln_rows_kernel<8, true>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
         else hipLaunchKernelGGL((ln_rows_kernel<16, true>), grid, block, 0, s, x, g, b, y, ob, R, D, mean_out, rstd_out);
