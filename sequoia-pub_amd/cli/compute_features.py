@@ -85,7 +85,7 @@ def main(argv=None):
             if args.feat_type == 'uni' and patches.shape[1] != 224:              # transforms.Resize(224), :54
                 from ..uni import resize_u8
                 patches = resize_u8(patches.to(device), 224)
-            feats = model.extract_patches_u8(patches, sub_batch=128).cpu().numpy()
+            feats = model.extract_patches_u8(patches, sub_batch=1000).cpu().numpy()      # clamped per mode / patch size by the extractor
             f_write = store.File(os.path.join(path_h5, WSI + '.h5'), "w")
             f_write.create_dataset(f"{args.feat_type}_features", data=feats)
             f_write.close()

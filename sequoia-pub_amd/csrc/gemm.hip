@@ -557,6 +557,7 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
         if (s > 1) a.splitk = (int)s;
     }
     if (g_force_split > 0 && a.splitk_ws && a.N % 8 == 0) a.splitk = g_force_split;
+    if (g_force_tile >= 33 && g_force_split <= 0) a.splitk = 1;      // a forced special kernel (probes): its tile code is not a 64-multiple pair, the split heuristic above does not apply
     if constexpr (sizeof(T) == 2) {
         // long-K products with enough 256 x 128 tiles: three-stage ring kernel (gemm_ring.hip); SQ_GEMM_RING=0 turns it off
         // 3x3 / stride-1 convolutions with enough 256 x 128 tiles: input tile resident in LDS (conv_halo.hip)
@@ -583,7 +584,7 @@ int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return laun
 
 int g_x3_small_max_k = -1, g_x3_halo = -1;
 extern int g_w4_waves;
-extern int g_p8_sched, g_p8_group_m, g_p8_skew;
+extern int g_p8_sched, g_p8_group_m, g_p8_skew, g_p8_bn;
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
@@ -592,6 +593,7 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
     else if (key == 7) g_x3_small_max_k = value;
+    else if (key == 13) g_p8_bn = value;             // gemm_p8.hip: forced tile width (128 / 256)
     else if (key == 12) g_p8_skew = value;           // gemm_p8.hip, persistent form: start-up skew in cycles per step
     else if (key == 11) g_p8_group_m = value;        // gemm_p8.hip: tile rows per group of the tile walk
     else if (key == 10) g_p8_sched = value;          // gemm_p8.hip: schedule variant

@@ -25,7 +25,8 @@
 // 32-byte halves): conflict-free 16-lane groups for the 16x16x32 fragment reads; with LDS-DMA the permutation sits on the
 // SOURCE address.  Half-tile A_a = block rows with (m >> 6) & 1 == a, B_b = columns with (n >> 5) & 1 == b, so that a wave's
 // 128 x 64 patch is contiguous in C although each of its quadrants lives in its own half-tile.
-// Epilogue: per-wave 16 x 64 fp32 slabs through LDS, 16-byte accesses, bias / residual / ReLU / GELU / bf16 copy as gemm_w4.hip.
+// Epilogue: per-wave 16 x 64 fp32 slabs through LDS, 16-byte accesses; bias, residual, pre-activation copy, LayerNorm(64), ReLU / GELU,
+// GELU' multiply, bf16 copy -- every operand requested before the slab is written.
 // PERSISTENT form (one block per CU; block i of the 32 an XCD runs takes tiles i, i + 32, ... of the XCD's run): with K = 1024 a tile's
 // 256 x 256 results are a third of its time when every CU stores them in the same few microseconds (tools/gemm_probe.py p8a:
 // 50432 x 4096 x 1024 with fp32 results 534 us, 367 us without the stores = an HBM write burst at 4.9 TB/s).  The persistent
@@ -51,21 +52,37 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ba
 }
 __device__ __forceinline__ u32x4 lds_read128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 
-constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
-constexpr int HALF_BYTES = 128 * BK * 2;         // 16 KiB: 128 rows x 64 k
-constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A_0 A_1 B_0 B_1
-constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 128 KiB (the epilogue slabs need 64 KiB of it)
+constexpr int BM = 256, BK = 64, NT = 512;
+constexpr int HALF_A = 128 * BK * 2;             // 16 KiB: 128 rows x 64 k
 constexpr int SLAB_BYTES = 16 * 64 * 4;          // one wave's 16 x 64 fp32 slab
+// BNT = 256: waves 2 x 4, 128 x 64 per wave, B half-tiles of 128 columns, 128 KiB for the two buffers.
+// BNT = 128: waves 4 x 2, 64 x 64 per wave, B half-tiles of 64 columns (one LDS-DMA instruction per thread), 96 KiB: the shape
+// for products whose 256 x 256 tiling cannot fill the chip (the ViS training step: 6400 x 1024 x 1024 = 100 tiles of 256 x 256
+// but 200 of 256 x 128 -- one per CU, all in one round).
+template <int BNT> struct P8Cfg {
+    static constexpr int WROWS = BNT == 256 ? 2 : 4, WCOLS = 8 / WROWS;
+    static constexpr int MF = 256 / WROWS / 16;          // m-fragments per wave (8 | 4); n-fragments: always 4 (64 columns)
+    static constexpr int MA = MF / 2;                    // m-fragments per A half-tile and wave (4 | 2)
+    static constexpr int SA = MA * 16;                   // rows of a wave's A sub-tile (64 | 32)
+    static constexpr int HALF_B = (BNT / 2) * BK * 2;    // 16 | 8 KiB
+    static constexpr int LB = BNT == 256 ? 2 : 1;        // LDS-DMA instructions per thread and B half-tile
+    static constexpr int BUF = 2 * HALF_A + 2 * HALF_B;  // A_0 A_1 B_0 B_1: 64 | 48 KiB
+    static constexpr int LDS = 2 * BUF;
+    static constexpr int WAIT = 2 + LB;                  // loads that may stay in flight behind the wait of phase 4: A_0 and B_1 of the K-tile after next
+};
 
-template <int EPI, bool PERSIST, bool DBG>
+template <int EPI, bool PERSIST, bool DBG, int BNT>
 __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
+    using Cfg = P8Cfg<BNT>;
+    constexpr int WCOLS = Cfg::WCOLS, MF = Cfg::MF, MA = Cfg::MA, SA = Cfg::SA, HALF_B = Cfg::HALF_B, BUF_BYTES = Cfg::BUF, LB = Cfg::LB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
+    const int grp = wave >> 2;           // the two groups of four waves (one wave of each per SIMD) that run one barrier apart
     const int dbg = DBG ? p.dbg : 0;     // ablation switches (tools/gemm_probe.py p8a): 1 no stores, 2 no LDS-DMA inside the loop, 4 no MFMA, 8 no fragment reads
 
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + BNT - 1) / BNT, tiles_m = (p.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
     const int z = PERSIST ? 0 : blockIdx.z;
     // each XCD (block id % 8) owns a contiguous run of tiles ...
@@ -84,7 +101,7 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
         const int gsz = min(tiles_m - first_m, gm);
         const int in_g = t - g * per_group;
         m0_ = (first_m + in_g % gsz) * BM;
-        n0_ = (in_g / gsz) * BN;
+        n0_ = (in_g / gsz) * BNT;
     };
     // persistent form: block (xcd, i) of the G blocks an XCD runs takes tiles i, i + G, i + 2 G, ... of the XCD's run -- the order
     // the dispatcher would have handed them out in
@@ -108,37 +125,53 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)(p.a_bytes - (size_t)z * p.sA * 2), 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)(p.b_bytes - (size_t)z * p.sB * 2), 0x00020000);
 
-    // ---- staging geometry.  Wave w stages row group w (16 LDS rows) of a half-tile, both 32-deep halves: two instructions
-    // that together request the whole 128-byte line of each of the 16 rows.  Lane l lands at byte 16 l of the 1 KiB
-    // sub-tile = LDS row l >> 2, PHYSICAL chunk l & 3; it must hold LOGICAL chunk (l & 3) ^ 2 [rows 8-15].
+    // ---- staging geometry.  A half-tile (128 LDS rows): wave w stages row group w (16 rows), both 32-deep halves -- two
+    // instructions that together request the whole 128-byte line of each row.  B half-tile: the same for 128 rows (BNT = 256);
+    // 64 rows (BNT = 128) are eight 1 KiB sub-tiles, wave w stages sub-tile w = (row group w >> 1, k half w & 1).
+    // Lane l lands at byte 16 l of the 1 KiB sub-tile = LDS row l >> 2, PHYSICAL chunk l & 3; it must hold LOGICAL chunk
+    // (l & 3) ^ 2 [rows 8-15].  Half-tile A_a = the rows whose SA-row block index is = a mod 2 (SA = a wave's sub-tile height);
+    // B_b = the columns whose 32-column block index is = b mod 2: a wave's patch is contiguous in C.
     const int s_lr = lane >> 2;
     const int s_ck = (lane & 3) ^ ((lane >> 5) << 1);
-    const int s_R = wave * 16 + s_lr;                                     // LDS row of the half-tile
+    const int s_RA = wave * 16 + s_lr;
+    const int s_RB = (LB == 2 ? wave : wave >> 1) * 16 + s_lr;
+    const int s_khB = wave & 1;                                            // BNT = 128: the k half this wave stages of a B half-tile
     uint32_t a_src[2], b_src[2];
     auto set_src = [&](int m0_, int n0_) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int m = m0_ + (s_R >> 6) * 128 + h * 64 + (s_R & 63);   // half-tile A_h: rows with (m >> 6) & 1 == h
-            const int n = n0_ + (s_R >> 5) * 64 + h * 32 + (s_R & 31);    // half-tile B_h: columns with (n >> 5) & 1 == h
+            const int m = m0_ + (s_RA / SA) * (2 * SA) + h * SA + (s_RA % SA);
+            const int n = n0_ + (s_RB >> 5) * 64 + h * 32 + (s_RB & 31);
             a_src[h] = m < p.M ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(s_ck * 8)) * 2u : OOB;
             b_src[h] = n < p.N ? ((uint32_t)n * (uint32_t)p.ldb + (uint32_t)(s_ck * 8)) * 2u : OOB;
         }
     };
     set_src(m0, n0);
     const int nk = (p.K + BK - 1) / BK;
-    // slot: 0 A_0, 1 A_1, 2 B_0, 3 B_1.  Tiles behind the last one (and the ragged end of K: K % 8 == 0, whole chunks) fetch
+    // slot: 0 A_0, 1 A_1, 2 B_0, 3 B_1.  K-tiles behind the last one (and the ragged end of K: K % 8 == 0, whole chunks) fetch
     // nothing -- the instruction is still issued so that the counted waits stay uniform.
     bool in_loop = false;
     auto stage = [&](int kt, int slot, int buf) {
         if ((dbg & 2) && in_loop) return;
-        char* dst = smem + buf * BUF_BYTES + slot * HALF_BYTES + wave * 2048;
-        const uint32_t src = slot < 2 ? a_src[slot & 1] : b_src[slot & 1];
-        const auto rs = slot < 2 ? rsA : rsB;
         const int k0 = kt * BK;
+        if (slot < 2) {
+            char* dst = smem + buf * BUF_BYTES + slot * HALF_A + wave * 2048;
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const bool ok = kt < nk && k0 + kh * 32 + s_ck * 8 < p.K;
-            glds16(rs, dst + kh * 1024, ok ? src : OOB, (k0 + kh * 32) * 2);
+            for (int kh = 0; kh < 2; ++kh) {
+                const bool ok = kt < nk && k0 + kh * 32 + s_ck * 8 < p.K;
+                glds16(rsA, dst + kh * 1024, ok ? a_src[slot] : OOB, (k0 + kh * 32) * 2);
+            }
+        } else if constexpr (LB == 2) {
+            char* dst = smem + buf * BUF_BYTES + 2 * HALF_A + (slot - 2) * HALF_B + wave * 2048;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const bool ok = kt < nk && k0 + kh * 32 + s_ck * 8 < p.K;
+                glds16(rsB, dst + kh * 1024, ok ? b_src[slot - 2] : OOB, (k0 + kh * 32) * 2);
+            }
+        } else {
+            char* dst = smem + buf * BUF_BYTES + 2 * HALF_A + (slot - 2) * HALF_B + wave * 1024;
+            const bool ok = kt < nk && k0 + s_khB * 32 + s_ck * 8 < p.K;
+            glds16(rsB, dst, ok ? b_src[slot - 2] : OOB, (k0 + s_khB * 32) * 2);
         }
     };
     // first operands of a tile: K-tile 0 complete, then what the steady state would have issued during "K-tile -1"
@@ -150,22 +183,22 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     // ---- fragment geometry (16x16x32: lane = (row l & 15, k group l >> 4), 8 consecutive k = 16 bytes)
     const int f_r = lane & 15, f_kg = lane >> 4;
     const int f_byte = (f_r * 64 + f_kg * 16) ^ ((f_r >> 3) << 5);
-    // A_a m-fragment ii (0..3): LDS rows wr * 64 + ii * 16 -> row group wr * 4 + ii;  B_b n-fragment jj (0..1): row group wc * 2 + jj
-    const int fa_base = (wr * 4) * 2048 + f_byte, fb_base = 2 * HALF_BYTES + (wc * 2) * 2048 + f_byte;
+    // A_a m-fragment ii: LDS rows wr * SA + ii * 16 -> row group wr * MA + ii;  B_b n-fragment jj (0..1): row group wc * 2 + jj
+    const int fa_base = (wr * MA) * 2048 + f_byte, fb_base = 2 * HALF_A + (wc * 2) * 2048 + f_byte;
 
-    f32x4v acc[8][4];
-    u32x4 fa[4][2] = {}, fb[2][2] = {};
+    f32x4v acc[MF][4];
+    u32x4 fa[MA][2] = {}, fb[2][2] = {};
     auto read_a = [&](int buf, int a) {
         if (dbg & 8) return;
-        const char* s = smem + buf * BUF_BYTES + a * HALF_BYTES + fa_base;
+        const char* s = smem + buf * BUF_BYTES + a * HALF_A + fa_base;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
+        for (int ii = 0; ii < MA; ++ii)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[ii][ks] = lds_read128(s + ii * 2048 + ks * 1024);
     };
     auto read_b = [&](int buf, int b) {
         if (dbg & 8) return;
-        const char* s = smem + buf * BUF_BYTES + b * HALF_BYTES + fb_base;
+        const char* s = smem + buf * BUF_BYTES + b * HALF_B + fb_base;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -175,7 +208,7 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
         constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
         if (dbg & 4) {
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) asm volatile("" ::"v"(fa[ii][0]), "v"(fa[ii][1]));
+            for (int ii = 0; ii < MA; ++ii) asm volatile("" ::"v"(fa[ii][0]), "v"(fa[ii][1]));
             asm volatile("" ::"v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[1][0]), "v"(fb[1][1]));
             return;
         }
@@ -183,12 +216,12 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
+            for (int ii = 0; ii < MA; ++ii)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     union { u32x4 u; bf16x8 h; } ua, ub;
                     ua.u = fa[ii][ks]; ub.u = fb[jj][ks];
-                    acc[a * 4 + ii][b * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.h, ub.h, acc[a * 4 + ii][b * 2 + jj], 0, 0, 0);
+                    acc[a * MA + ii][b * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.h, ub.h, acc[a * MA + ii][b * 2 + jj], 0, 0, 0);
                 }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -224,18 +257,28 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
         P8_SYNC_MMA(I1, I1);
         read_b(buf, 0);
         stage(kt + 2, 3, buf);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything up to B_0 of K-tile kt + 1 has landed (this wave's part)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::WAIT) : "memory");      // everything up to B_0 of K-tile kt + 1 has landed (this wave's part)
         P8_SYNC_MMA(I1, I0);
     };
 
-    // ---- epilogue geometry.  C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r.  Wave patch: rows m0 + wr*128 ..
-    // +128, columns n0 + wc*64 .. +64; slab = one m-fragment (16 rows) x 64 columns, private to the wave: 4 KiB.
+    // ---- epilogue geometry.  C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r.  Wave patch: MF m-fragments of
+    // 16 rows from m0 + wr * (16 MF), columns n0 + wc*64 .. +64; slab = one m-fragment x 64 columns, private to the wave: 4 KiB.
     float* slab = reinterpret_cast<float*>(smem + (PERSIST ? 2 * BUF_BYTES : 0) + wave * SLAB_BYTES);
     const int e_c8 = lane & 7, e_r8 = lane >> 3;         // read-out: 8 lanes cover a slab row (64 columns), 8 rows per pass
     auto epilogue = [&](int m0_, int n0_) {
         const int e_n = n0_ + wc * 64 + e_c8 * 8;
         const int e_cnt = min(8, p.N - e_n);
-        const bool fast = p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && !p.Cpre && !p.gelu_grad_of && ((EPI & 4) != 0) == (p.ln64_g != nullptr);
+        const bool fast = p.vec_epi != 0 && e_cnt == 8 && !p.rowbias && ((EPI & 4) != 0) == (p.ln64_g != nullptr) &&
+            ((EPI & 2) != 0 || !p.gelu_grad_of);
+        float bias8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+        if (fast && p.bias) {
+            const float* bsrc = p.bias + (long long)z * p.sBias + e_n;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(bsrc), t1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bias8[e] = t0[e]; bias8[4 + e] = t1[e]; }
+        }
         // EPI & 4: per-head LayerNorm(64) + affine between the bias / residual and the activation (src/tformer_lin.py:20-21: the f
         // projection's local_norm): a slab row IS one head -- the wave's 64 columns -- and lives in 8 consecutive lanes
         float lng[8], lnb[8];
@@ -247,40 +290,38 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                 for (int e = 0; e < 4; ++e) { lng[e] = g0[e]; lng[4 + e] = g1[e]; lnb[e] = b0[e]; lnb[4 + e] = b1[e]; }
             }
         }
-        float bias8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-        if (fast && p.bias) {
-            const float* bsrc = p.bias + (long long)z * p.sBias + e_n;
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(bsrc), t1 = *reinterpret_cast<const f32x4*>(bsrc + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { bias8[e] = t0[e]; bias8[4 + e] = t1[e]; }
-        }
         const float* res32 = (fast && p.res && p.res_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.res) + (long long)z * p.sRes : nullptr;
         const bf16_t* res16 = (fast && p.res && p.res_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.res) + (long long)z * p.sRes : nullptr;
+        const float* gg32 = ((EPI & 2) && fast && p.gelu_grad_of && p.gg_dtype == SQ_F32) ? reinterpret_cast<const float*>(p.gelu_grad_of) + (long long)z * p.sGg : nullptr;
+        const bf16_t* gg16 = ((EPI & 2) && fast && p.gelu_grad_of && p.gg_dtype == SQ_BF16) ? reinterpret_cast<const bf16_t*>(p.gelu_grad_of) + (long long)z * p.sGg : nullptr;
         float* c32 = p.out_dtype == SQ_F32 ? reinterpret_cast<float*>(p.C) + (long long)z * p.sC : nullptr;
         bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
+        float* cpre32 = (p.Cpre && p.pre_dtype == SQ_F32) ? reinterpret_cast<float*>(p.Cpre) + (long long)z * p.sPre : nullptr;
+        bf16_t* cpre16 = (p.Cpre && p.pre_dtype == SQ_BF16) ? reinterpret_cast<bf16_t*>(p.Cpre) + (long long)z * p.sPre : nullptr;
+        auto ld8 = [&](const float* s32, const bf16_t* s16, long long off, float (&d)[8]) {
+            if (s16) {
+                const u32x4 tt = *reinterpret_cast<const u32x4*>(s16 + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { d[2 * e] = __uint_as_float(tt[e] << 16); d[2 * e + 1] = __uint_as_float(tt[e] & 0xffff0000u); }
+            } else if (s32) {
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(s32 + off), t1 = *reinterpret_cast<const f32x4*>(s32 + off + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { d[e] = t0[e]; d[4 + e] = t1[e]; }
+            }
+        };
         auto slab_out = [&](auto ic) {                       // compile-time m-fragment index: a run-time one would push the accumulators to scratch
             constexpr int i = decltype(ic)::value;
-            const int mrow0 = m0_ + wr * 128 + i * 16;
-            float aux[2][8];
-            if (fast) {                                      // residual rows requested before the slab is written
+            const int mrow0 = m0_ + wr * (MF * 16) + i * 16;
+            float aux[2][8], gsrc[2][8];
+            if (fast) {                                      // residual / GELU' source rows are requested before the slab is written
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) aux[u][e] = 0.f;
+                    for (int e = 0; e < 8; ++e) { aux[u][e] = 0.f; gsrc[u][e] = 0.f; }
                     const int m = mrow0 + u * 8 + e_r8;
                     if (m < p.M) {
-                        if (res16) {
-                            const u32x4 tt = *reinterpret_cast<const u32x4*>(res16 + (long long)m * p.ldres + e_n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { aux[u][2 * e] = __uint_as_float(tt[e] << 16); aux[u][2 * e + 1] = __uint_as_float(tt[e] & 0xffff0000u); }
-                        } else if (res32) {
-                            const float* src = res32 + (long long)m * p.ldres + e_n;
-                            const f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { aux[u][e] = t0[e]; aux[u][4 + e] = t1[e]; }
-                        }
+                        ld8(res32, res16, (long long)m * p.ldres + e_n, aux[u]);
+                        if constexpr ((EPI & 2) != 0) ld8(gg32, gg16, (long long)m * p.ldgg + e_n, gsrc[u]);
                     }
                 }
             }
@@ -298,11 +339,19 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8 + 4);
                 float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 if (!fast) {
-                    epi_apply<EPI, true>(p, z, m, e_n, v, e_cnt, p.vec_epi != 0 && e_cnt == 8);
+                    epi_apply<EPI & 3, true>(p, z, m, e_n, v, e_cnt, p.vec_epi != 0 && e_cnt == 8);
                     continue;
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (p.alpha * v[e] + bias8[e]) + aux[u][e];
+                if (cpre32) {                                 // the pre-activation value the backward pass wants (f32 or bf16)
+                    float* d = cpre32 + (long long)m * p.ldpre + e_n;
+                    *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+                if (cpre16)
+                    *reinterpret_cast<u32x4*>(cpre16 + (long long)m * p.ldpre + e_n) =
+                        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                 if constexpr ((EPI & 4) != 0) {          // two-pass mean / variance as nn.LayerNorm, eps 1e-5 (the arithmetic of gemm.hip's epilogue)
                     float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                     sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
@@ -322,6 +371,12 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+                if constexpr ((EPI & 2) != 0) {
+                    if (gg32 || gg16) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= sq_gelu_grad<true>(gsrc[u][e]);
+                    }
+                }
                 if (c32) {
                     float* d = c32 + (long long)m * p.ldc + e_n;
                     *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
@@ -334,26 +389,28 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
         };
         slab_out(std::integral_constant<int, 0>{}); slab_out(std::integral_constant<int, 1>{});
         slab_out(std::integral_constant<int, 2>{}); slab_out(std::integral_constant<int, 3>{});
-        slab_out(std::integral_constant<int, 4>{}); slab_out(std::integral_constant<int, 5>{});
-        slab_out(std::integral_constant<int, 6>{}); slab_out(std::integral_constant<int, 7>{});
+        if constexpr (MF == 8) {
+            slab_out(std::integral_constant<int, 4>{}); slab_out(std::integral_constant<int, 5>{});
+            slab_out(std::integral_constant<int, 6>{}); slab_out(std::integral_constant<int, 7>{});
+        }
     };
 
     stage_first();
     while (true) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // K-tile 0 has landed (persistent form: and the previous tile's stores are out)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::WAIT) : "memory");      // K-tile 0 has landed (persistent form: and the previous tile's stores are out)
         __builtin_amdgcn_s_barrier();
-        if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3
+        if (grp == 1) __builtin_amdgcn_s_barrier();         // waves 4-7 run one barrier behind waves 0-3
         in_loop = true;
         for (int kt = 0; kt < nk; kt += 2) {
             tile_phases(kt, I0{});
             if (kt + 1 < nk) tile_phases(kt + 1, I1{});
         }
         in_loop = false;
-        if (wr == 0) __builtin_amdgcn_s_barrier();
+        if (grp == 0) __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing empty loads have written their zeros
         __syncthreads();                                    // all fragment reads done: the buffers are free
         if constexpr (!PERSIST) {
@@ -378,12 +435,13 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
 
 }  // namespace
 
-// true when the eight-phase 256 x 256 x 64 kernel takes the product: bf16, plain (no convolution view), K in whole 16-byte
-// chunks, enough tiles to give (nearly) every CU one, and only the epilogues its prefetching fast path covers
-bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype) {
-    if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.rowbias || a.Cpre || a.gelu_grad_of || !a.vec_epi) return false;
-    if (a.ln64_g && (a.N % 64 || !a.ln64_b)) return false;
-    static int on = -1, min_tiles = 0, min_k = 0;
+// Which shape of the eight-phase kernel takes the product, if any: 256 (256 x 256 tiles), 128 (256 x 128 tiles), 0 (none).  bf16,
+// plain (no convolution view), K in whole 16-byte chunks, no split-K, a vector epilogue without row bias; 256 x 256 when that
+// gives (nearly) every CU a tile, else 256 x 128 when THAT does and the product is too small for more than ~1.5 rounds of it.
+int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
+    if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.rowbias || !a.vec_epi) return 0;
+    if (a.ln64_g && (a.N % 64 || !a.ln64_b)) return 0;
+    static int on = -1, min_tiles = 0, min_k = 0, on128 = 0;
     if (on < 0) {
         const char* e = getenv("SQ_GEMM_P8");
         on = (e && e[0] == '0') ? 0 : 1;          // SQ_GEMM_P8=0: back to gemm_w4.hip (the A/B of tools/gemm_probe.py p8)
@@ -391,33 +449,44 @@ bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype) {
         min_tiles = mt ? atoi(mt) : 232;
         const char* mk = getenv("SQ_GEMM_P8_MIN_K");
         min_k = mk ? atoi(mk) : 512;
+        // the 256 x 128 shape is opt-in: on the ViS training step's 6400 x 1024 x 1024 products it equals the 128 x 128 kernel in
+        // isolation (23.1 vs 23.0 us; its phases hold 8 MFMAs, too few to amortise two barriers) and loses in the step (3.80 vs 3.55 ms):
+        // a block that owns a whole CU leaves no room for the weight-gradient products of the helper stream
+        const char* e1 = getenv("SQ_GEMM_P8_BN128");
+        on128 = (e1 && e1[0] == '1') ? 1 : 0;
     }
-    if (!on) return false;
-    const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.batch;
-    return a.K % 8 == 0 && a.K >= min_k && a.N % BN == 0 && tiles >= min_tiles;
+    if (!on || a.K % 8 || a.K < min_k) return 0;
+    const long long rows = (a.M + BM - 1) / BM;
+    if (a.N % 256 == 0 && rows * (a.N / 256) * a.batch >= min_tiles) return 256;
+    const long long t128 = rows * (a.N / 128) * a.batch;
+    if (on128 && a.N % 128 == 0 && t128 >= 150 && t128 <= 400) return 128;
+    return 0;
 }
+bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype) { return sq_gemm_p8_shape(a, dtype) != 0; }
 
 int g_p8_group_m = -1;             // sq_dbg_set key 11: tile rows per group of the tile walk (-1 = environment SQ_GEMM_P8_GROUP_M or 8)
 int g_p8_sched = -1;               // sq_dbg_set key 10 (probes): 0 = one block per tile, 1 = persistent blocks; -1 = environment (SQ_GEMM_P8_PERSIST) or 1
-int g_p8_skew = -1;                // sq_dbg_set key 12: start-up skew of the persistent form in cycles per step (-1 = environment SQ_GEMM_P8_SKEW or the default)
+int g_p8_skew = -1;                // sq_dbg_set key 12: start-up skew of the persistent form in cycles per step (-1 = environment SQ_GEMM_P8_SKEW or none)
+int g_p8_bn = -1;                  // sq_dbg_set key 13: forced tile width (128 / 256) when the kernel is forced (tile 88); -1 = by shape
 namespace {
-template <int EPI, bool PERSIST, bool DBG>
+template <int EPI, bool PERSIST, bool DBG, int BNT>
 int launch_p8(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-    constexpr int lds = PERSIST ? LDS_BYTES + 8 * SLAB_BYTES : LDS_BYTES;
+    constexpr int lds = P8Cfg<BNT>::LDS + (PERSIST ? 8 * SLAB_BYTES : 0);
     static SqDevOnce attr;       // hipFuncSetAttribute is per device
     if (attr.needed()) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_p8_kernel<EPI, PERSIST, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_p8_kernel<EPI, PERSIST, DBG, BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr.done();
     }
-    hipLaunchKernelGGL((gemm_p8_kernel<EPI, PERSIST, DBG>), grid, dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((gemm_p8_kernel<EPI, PERSIST, DBG, BNT>), grid, dim3(NT), lds, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
-template <bool PERSIST>
+template <bool PERSIST, int BNT>
 int launch_p8_pick(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-    if (a.dbg) return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, true>(a, grid, stream) : launch_p8<0, PERSIST, true>(a, grid, stream);
-    if (a.ln64_g) return launch_p8<5, PERSIST, false>(a, grid, stream);          // LayerNorm(64) [+ GELU when act says so]
-    return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, false>(a, grid, stream) : launch_p8<0, PERSIST, false>(a, grid, stream);
+    if (a.dbg) return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, true, BNT>(a, grid, stream) : launch_p8<0, PERSIST, true, BNT>(a, grid, stream);
+    if (a.ln64_g) return launch_p8<5, PERSIST, false, BNT>(a, grid, stream);          // LayerNorm(64) [+ GELU when act says so]
+    if (a.gelu_grad_of) return launch_p8<2, PERSIST, false, BNT>(a, grid, stream);    // GELU' multiply (backward pass)
+    return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, false, BNT>(a, grid, stream) : launch_p8<0, PERSIST, false, BNT>(a, grid, stream);
 }
 int p8_cus() {
     static int cus[64] = {};
@@ -433,20 +502,24 @@ int p8_cus() {
 
 int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
-    SQ_REQUIRE(!a.ln64_g || (a.ln64_b && a.N % BN == 0 && a.vec_epi), "gemm_p8: the LayerNorm(64) epilogue needs N %% 256 == 0 and 16-byte aligned epilogue operands");
+    SQ_REQUIRE(!a.ln64_g || (a.ln64_b && a.N % 64 == 0 && a.vec_epi), "gemm_p8: the LayerNorm(64) epilogue needs N %% 64 == 0 and 16-byte aligned epilogue operands");
+    SQ_REQUIRE(!a.rowbias, "gemm_p8: no row-bias epilogue");
     static int env_gm = -1, env_persist = -1, env_skew = -2;
     if (env_gm < 0) { const char* e = getenv("SQ_GEMM_P8_GROUP_M"); env_gm = e ? atoi(e) : 8; }
     if (env_persist < 0) { const char* e = getenv("SQ_GEMM_P8_PERSIST"); env_persist = e ? atoi(e) : 1; }
     if (env_skew == -2) { const char* e = getenv("SQ_GEMM_P8_SKEW"); env_skew = e ? atoi(e) : -1; }
     a.tile_group_m = g_p8_group_m > 0 ? g_p8_group_m : env_gm;
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    int bn = sq_gemm_p8_shape(a, SQ_BF16);
+    if (g_p8_bn == 128 || g_p8_bn == 256) bn = g_p8_bn;         // probes / tests
+    if (bn == 0) bn = 256;                                        // forced (tile 88) on a shape the heuristics would not pick
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + bn - 1) / bn);
     const bool persist = (g_p8_sched >= 0 ? g_p8_sched : env_persist) != 0 && a.batch == 1;
     const int cus = p8_cus() & ~7;
     if (persist && tiles > cus && cus >= 8) {
         // start-up skew (experiment knob, default none): measured SLOWER by more than the delay itself (50432 x 4096 x 1024: 454 us
         // in step, 527 us with a quarter-tile skew) -- blocks of an XCD that drift apart stop sharing operand panels in L2
         a.skew_cycles = g_p8_skew >= 0 ? g_p8_skew : env_skew >= 0 ? env_skew : 0;
-        return launch_p8_pick<true>(a, dim3(cus, 1, 1), stream);
+        return bn == 256 ? launch_p8_pick<true, 256>(a, dim3(cus, 1, 1), stream) : launch_p8_pick<true, 128>(a, dim3(cus, 1, 1), stream);
     }
-    return launch_p8_pick<false>(a, dim3(tiles, 1, a.batch), stream);
+    return bn == 256 ? launch_p8_pick<false, 256>(a, dim3(tiles, 1, a.batch), stream) : launch_p8_pick<false, 128>(a, dim3(tiles, 1, a.batch), stream);
 }

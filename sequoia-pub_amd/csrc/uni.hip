@@ -408,6 +408,11 @@ extern "C" int sq_uni_forward(const sq_uni_config* c, int dtype, const float* pa
     SQ_REQUIRE(params && params_exec && bias_exec && out && workspace, "uni_forward: null pointer");
     SQ_REQUIRE((patches_u8 != nullptr) != (patches_f32_nchw != nullptr), "uni_forward: give exactly one of patches_u8 / patches_f32_nchw");
     SQ_REQUIRE(n >= 1, "uni_forward: n=%d", n);
+    {   // every activation is addressed through a 31-bit buffer descriptor: the widest one is [n * tokens, max(3 dim, mlp_dim)]
+        const size_t tokens = (size_t)(c->img_size / PS) * (c->img_size / PS) + 1;
+        const size_t widest = (size_t)n * tokens * (size_t)(c->mlp_dim > 3 * c->dim ? c->mlp_dim : 3 * c->dim) * sq_dtype_size(dtype);
+        SQ_REQUIRE(widest < (1ull << 31), "uni_forward: a launch group of %d patches exceeds the 2 GiB buffer-descriptor limit (ViT-L/16 at 224: <= 1330 patches in bf16, <= 665 in fp32)", n);
+    }
     sq_uni_layout lay;
     if (int e = sq_uni_layout_init(c, &lay)) return e;
     UniBufs w;

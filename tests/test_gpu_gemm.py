@@ -193,8 +193,8 @@ def test_four_stage_256_tile_variant_matches_default_tile(M, N, K, act, waves):
 
 @pytest.mark.parametrize("M,N,K,act,out", [(256 * 9 + 37, 512, 320, 2, "bf16"), (700, 256 + 64, 1024, 1, "bf16"), (3000, 768, 72, 0, "f32"),
                                            (256 * 40, 1024, 4096, 0, "f32"), (256 * 70 + 37, 1024, 320, 2, "bf16"), (256 * 33, 2048, 1088, 1, "f32")])
-@pytest.mark.parametrize("sched", [0, 1])
-def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched):
+@pytest.mark.parametrize("sched,bn", [(0, 256), (1, 256), (1, 128)])
+def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched, bn):
     """gemm_p8.hip (256 x 256 x 64 tile, two buffers of four half-tiles, eight phases per pair of K-tiles, the two wave rows one
     barrier apart, 16x16x32 MFMAs), forced through the experiment knob: ragged M / N / K (an odd number of K-tiles, a K-tile
     with a single 16-byte chunk), bias, bf16 residual, ReLU / GELU, bf16 / fp32 output against the fp32 product of the same
@@ -212,6 +212,7 @@ def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched):
     odt, ocode = (torch.bfloat16, _lib.SQ_BF16) if out == "bf16" else (torch.float32, _lib.SQ_F32)
     outs = []
     lib.sq_dbg_set(10, sched)            # 0: one block per tile; 1: persistent blocks (when there are more tiles than CUs: the last two cases)
+    lib.sq_dbg_set(13, bn)               # tile width: 256 (waves 2 x 4) or 128 (waves 4 x 2, one LDS-DMA instruction per B half-tile)
     try:
         for tile in (22, 88, 88, 88):
             lib.sq_dbg_set(0, tile)
@@ -223,6 +224,7 @@ def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched):
     finally:
         lib.sq_dbg_set(0, 0)
         lib.sq_dbg_set(10, -1)
+        lib.sq_dbg_set(13, -1)
     pre = A.float() @ W.float().T + bias + res.float()
     ref = torch.relu(pre) if act == 2 else torch.nn.functional.gelu(pre) if act == 1 else pre
     assert torch.isfinite(outs[1]).all()

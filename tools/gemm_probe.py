@@ -70,6 +70,23 @@ if __name__ == "__main__":
         for M, N, K in [(50432, 4096, 1024), (50432, 3072, 1024)]:           # bf16 output (what the UNI blocks write)
             probe(M, N, K, _lib.SQ_BF16, tiles=(55, 88), dbgs=(0,), out_bf16=True, scheds=(0, 1))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8s":
+        # why is a single round of tiles slow?  fixed vs per-K-tile cost (K sweep) and the ablation switches on 6400 x 1024 x K
+        for bn in (128, 256):
+            lib.sq_dbg_set(13, bn)
+            for K in (256, 1024, 4096):
+                print("bn", bn)
+                probe(6400, 1024, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0, 1, 2, 4, 8, 14), scheds=(1,))
+        lib.sq_dbg_set(13, -1)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8n":
+        # the 256 x 128 shape of gemm_p8.hip (forced width 128) on the ViS training step's products, against the engine's other kernels
+        for M, N, K in [(6400, 1024, 1024), (6400, 1024, 1024), (12800, 1024, 1024), (3200, 1024, 1024), (6400, 2048, 1024)]:
+            lib.sq_dbg_set(13, 128)
+            probe(M, N, K, _lib.SQ_BF16, tiles=(22, 88, 22, 88), dbgs=(0,), scheds=(1,))
+            probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0,), scheds=(1,), out_bf16=True)
+        lib.sq_dbg_set(13, -1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "p8p":
         # persistent form of gemm_p8.hip (sched 1) against one block per tile (sched 0), and its start-up skew (cycles per step; 0 = none)
         for out_bf16 in (False, True):
