@@ -446,7 +446,7 @@ int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
         const char* e = getenv("SQ_GEMM_P8");
         on = (e && e[0] == '0') ? 0 : 1;          // SQ_GEMM_P8=0: back to gemm_w4.hip (the A/B of tools/gemm_probe.py p8)
         const char* mt = getenv("SQ_GEMM_P8_MIN_TILES");
-        min_tiles = mt ? atoi(mt) : 232;
+        min_tiles = mt ? atoi(mt) : 176;            // tools/gemm_probe.py p8m: ahead of the kernels it replaces from 192 tiles (24500 x 512 x 2048: 932 vs 837 TF), level at 200 x K 1024, behind at 100
         const char* mk = getenv("SQ_GEMM_P8_MIN_K");
         min_k = mk ? atoi(mk) : 512;
         // the 256 x 128 shape is opt-in: on the ViS training step's 6400 x 1024 x 1024 products it equals the 128 x 128 kernel in

@@ -9,7 +9,7 @@ from sequoia_pub_amd import _lib
 
 lib = _lib.lib()
 lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
-WS = torch.empty(128 << 20, dtype=torch.uint8, device='cuda')
+WS = torch.empty(128 << 20, dtype=torch.uint8, device='cuda')        # split-K scratch (the launcher ignores it for forced special kernels)
 
 
 def time_fn(fn, iters=30):
@@ -69,6 +69,15 @@ if __name__ == "__main__":
             probe(M, N, K, _lib.SQ_BF16, tiles=(0, 55, 88, 88), dbgs=(0,), scheds=(0, 1))
         for M, N, K in [(50432, 4096, 1024), (50432, 3072, 1024)]:           # bf16 output (what the UNI blocks write)
             probe(M, N, K, _lib.SQ_BF16, tiles=(55, 88), dbgs=(0,), out_bf16=True, scheds=(0, 1))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8m":
+        # mid-size products: where does the 256 x 256 kernel (tile 88) start to beat the engine's pick (tile 0 = the kernel it replaces
+        # below SQ_GEMM_P8_MIN_TILES tiles)?  tiles of 256 x 256 in brackets
+        os.environ["SQ_GEMM_P8"] = "0"
+        for M, N, K in [(4096, 4096, 4096), (6400, 1024, 1024), (12800, 1024, 1024), (25600, 1024, 1024), (16384, 2048, 2048), (8192, 4096, 1024),
+                        (24500, 2048, 1024), (24500, 512, 2048), (12800, 2048, 2048)]:
+            print("tiles", ((M + 255) // 256) * (N // 256))
+            probe(M, N, K, _lib.SQ_BF16, tiles=(0, 88, 0, 88), dbgs=(0,), scheds=(1,), out_bf16=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "p8s":
         # why is a single round of tiles slow?  fixed vs per-K-tile cost (K sweep) and the ablation switches on 6400 x 1024 x K
