@@ -140,6 +140,54 @@ def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
     return roof, recs
 
 
+def measure_traffic(roof, args):
+    """--measure-traffic: HBM-side bytes per launch of the line's dominant kernel from the PMC counters of THIS build, in place of
+    the figure of the committed pass: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC slots) over one small
+    step of the same workload in child processes, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-byte
+    request on gfx950: doubled; KiB units).  Covers the kernel classes whose (symbol, grid) can be derived from their name: the
+    halo-staged 3x3 of the split modes (the headline's dominant class) and the plain split-mode products."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    m = re.match(r"(conv|gemm)_(f16x3|bf16x3)_M(\d+)_N(\d+)_K(\d+)$", roof.get("kernel", ""))
+    if not m or shutil.which("rocprofv3") is None:
+        return False
+    kind, M, N, K = m.group(1), int(m.group(3)), int(m.group(4)), int(m.group(5))
+    if kind == "conv":
+        symbol, grid = "conv_halo_x3_kernel", -(-M // 256) * (N // 128 if N % 128 == 0 else -(-N // 64)) * 512
+    elif K >= 512 and N > 64:
+        symbol, grid = "gemm_x3_kernel<256", -(-M // 256) * -(-N // 128) * 512
+    else:
+        symbol, grid = "gemm_x3_kernel<128", -(-M // 128) * -(-N // (128 if N > 64 else 64)) * 256
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="sq_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", args.workload, "--dtype", args.dtype, "--slides", "1", "--steps", "1", "--warmup", "1",
+                   "--patches", str(args.patches), "--patch-size", str(args.patch_size), "--sub-batch", str(args.sub_batch),
+                   "--no-secondary", "--no-cpu-baseline", "--no-accuracy"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+            vals = []
+            for f in glob.glob(out + "/**/*_counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and symbol in r["Kernel_Name"] and int(r["Grid_Size"]) == grid:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return False
+            got[counter] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    roof["traffic"] = round(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
+    roof["traffic_measured"] = True
+    roof["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes of this build, {symbol}... grid {grid}"
+    return True
+
+
 def timed_cpu_sample(fn, units_per_call, budget_s=12.0, candidates=(8, 16, 32, 64, 128)):
     """Time `fn` (a CPU oracle call) on this host: try a few torch thread counts once each (the
     reference's many small per-head GEMMs do not scale to every core of a big host), keep the
@@ -652,6 +700,8 @@ def main():
     ap.add_argument("--no-stream", action="store_true", help="pipeline workload: finish every step's slides before the next step starts")
     ap.add_argument("--resident", action="store_true", help="pipeline workload: patches already in HBM when the timed region starts "
                     "(default: uploaded from pinned host memory every step, as BASELINE config 3 states)")
+    ap.add_argument("--measure-traffic", action="store_true", help="collect roofline.traffic with two rocprofv3 --pmc passes of this build "
+                    "(adds minutes; default: the figure of the committed pass under profiles/, traffic_measured false)")
     ap.add_argument("--no-accuracy", action="store_true", help="pipeline workload: skip the accuracy_vs_reference checker leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the secondary measurements")
@@ -701,6 +751,11 @@ def main():
             "host_numa_binding": numa,
             "ranks": torch.distributed.get_world_size() if world > 1 else 1,
             "backend": (torch.distributed.get_backend() if world > 1 else None)}
+    if args.measure_traffic and rank == 0 and world == 1 and line.get("roofline"):
+        try:
+            measure_traffic(line["roofline"], args)
+        except Exception as e:                          # a profiler problem must not cost the line
+            line["roofline"]["traffic_error"] = f"{type(e).__name__}: {e}"
     if "check" in res:
         line["check"] = res["check"]
     if args.workload == "pipeline" and args.embedder == "resnet" and rank == 0 and world == 1 and not args.no_accuracy:

@@ -584,7 +584,7 @@ int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return laun
 
 int g_x3_small_max_k = -1, g_x3_halo = -1;
 extern int g_w4_waves;
-extern int g_p8_sched, g_p8_group_m, g_p8_skew, g_p8_bn;
+extern int g_p8_sched, g_p8_group_m, g_p8_skew, g_p8_bn, g_p8_on;
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
@@ -593,6 +593,7 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
     else if (key == 7) g_x3_small_max_k = value;
+    else if (key == 14) g_p8_on = value;             // gemm_p8.hip on / off (-1: environment)
     else if (key == 13) g_p8_bn = value;             // gemm_p8.hip: forced tile width (128 / 256)
     else if (key == 12) g_p8_skew = value;           // gemm_p8.hip, persistent form: start-up skew in cycles per step
     else if (key == 11) g_p8_group_m = value;        // gemm_p8.hip: tile rows per group of the tile walk

@@ -438,6 +438,7 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
 // Which shape of the eight-phase kernel takes the product, if any: 256 (256 x 256 tiles), 128 (256 x 128 tiles), 0 (none).  bf16,
 // plain (no convolution view), K in whole 16-byte chunks, no split-K, a vector epilogue without row bias; 256 x 256 when that
 // gives (nearly) every CU a tile, else 256 x 128 when THAT does and the product is too small for more than ~1.5 rounds of it.
+int g_p8_on = -1;                  // sq_dbg_set key 14 (tests): 0 / 1 overrides SQ_GEMM_P8
 int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
     if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.rowbias || !a.vec_epi) return 0;
     if (a.ln64_g && (a.N % 64 || !a.ln64_b)) return 0;
@@ -455,7 +456,7 @@ int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
         const char* e1 = getenv("SQ_GEMM_P8_BN128");
         on128 = (e1 && e1[0] == '1') ? 1 : 0;
     }
-    if (!on || a.K % 8 || a.K < min_k) return 0;
+    if (!(g_p8_on >= 0 ? g_p8_on : on) || a.K % 8 || a.K < min_k) return 0;
     const long long rows = (a.M + BM - 1) / BM;
     if (a.N % 256 == 0 && rows * (a.N / 256) * a.batch >= min_tiles) return 256;
     const long long t128 = rows * (a.N / 128) * a.batch;

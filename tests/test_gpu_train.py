@@ -260,6 +260,47 @@ def test_full_size_batch64_bf16_step_vs_oracle():
     assert worst[1] < 8e-2, worst
 
 
+def test_batch192_bf16_step_on_the_eight_phase_gemm_vs_oracle():
+    """A training step large enough for gemm_p8.hip to take the model's big products (batch 192: M = 19200 = 300 tiles of
+    256 x 256): its pre-activation copy (F, U), LayerNorm(64) + GELU and GELU' epilogues run in the forward and backward pass.
+    Depth 2, G = 512 (the oracle's autograd on the CPU stays in seconds): predictions, loss and every gradient tensor against the
+    fp32 oracle at the bf16 tolerances, and against the same step with the kernel switched off (the kernels it replaces)."""
+    import ctypes
+    _lib.require_gpu()
+    lib = _lib.lib()
+    lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
+    cfg = dict(num_outputs=512, input_dim=1024, depth=2, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=17), seed=6)
+    B = 192
+    x = torch.from_numpy(synth.cluster_tokens(5, B, 1024))
+    y = torch.from_numpy(synth.rna_targets(8, B, 512))
+    torch.set_num_threads(min(32, os.cpu_count()))
+    loss_ref, pred_ref, grads_ref = vis_oracle.vis_loss_and_grads(sd, x, y)
+    out = {}
+    try:
+        for on in (1, 0):
+            lib.sq_dbg_set(14, on)
+            m = ViS(**cfg, device="cuda:0", compute_dtype="bf16")
+            m.load_state_dict(sd)
+            m.to("cuda:0")
+            pred = m._run_forward(x.cuda(), save=True)
+            loss, gpred = sq_train.mse_loss_grad(m, pred, y.cuda())
+            gflat, _ = sq_train.vis_backward(m, gpred, B, False)
+            torch.cuda.synchronize()
+            out[on] = (pred.cpu().numpy(), float(loss), {k: v.cpu().numpy() for k, v in m.grad_views(gflat).items()})
+    finally:
+        lib.sq_dbg_set(14, -1)
+    pred, loss, gv = out[1]
+    e_pred = rel_err(pred, pred_ref.detach().numpy())
+    worst = max(((rel_err(gv[k], grads_ref[k].numpy()), k) for k in grads_ref), key=lambda t: t[0])
+    worst_ab = max(((rel_err(gv[k], out[0][2][k]), k) for k in grads_ref), key=lambda t: t[0])
+    print(f"B=192 bf16 step on gemm_p8: pred rel err {e_pred:.3e}; loss {loss:.5f} vs {float(loss_ref):.5f}; worst gradient tensor vs oracle "
+          f"{worst[0]:.3e} at {worst[1]}, vs the step without the kernel {worst_ab[0]:.3e} at {worst_ab[1]}")
+    assert e_pred < 2e-2 and abs(loss - float(loss_ref)) < 2e-3 * float(loss_ref)
+    assert worst[0] < 8e-2, worst
+    assert worst_ab[0] < 5e-2 and rel_err(pred, out[0][0]) < 1e-2
+
+
 def test_helper_streams_do_not_change_results(monkeypatch):
     """bf16 training step at a realistic size: weight gradients / summary branch on helper streams vs everything on
     one stream must give bit-identical losses and parameters (the kernels are deterministic; streams only reorder)."""

@@ -221,7 +221,7 @@ def test_resnet50_x3_fused_chain_is_bit_identical(monkeypatch, mode):
     _lib.require_gpu()
     m, sd = _model(mode)
     p = torch.from_numpy(synth.patches_u8(5, n_patches=3, size=224)).cuda()
-    p256 = torch.from_numpy(synth.patches_u8(6, n_patches=1, size=256)).cuda()          # 64 x 64 maps: wider than the tail form takes
+    p256 = torch.from_numpy(synth.patches_u8(6, n_patches=1, size=256)).cuda()          # 64 x 64 maps (256-px patches): the WIDE tail form (208-row planes, three-stage ring, tap-major K like the implicit GEMM these maps take unfused)
     outs = {}
     for tag, env in (("tail", {}), ("chain", {"SQ_RESNET_NO_TAIL": "1"}), ("chain_no_ds", {"SQ_RESNET_NO_TAIL": "1", "SQ_RESNET_NO_CHAIN_DS": "1"}),
                      ("no_dual", {"SQ_RESNET_NO_DUAL": "1"}), ("dual_everywhere", {"SQ_RESNET_NO_CHAIN": "1"}),
