@@ -458,7 +458,10 @@ int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
     }
     if (!(g_p8_on >= 0 ? g_p8_on : on) || a.K % 8 || a.K < min_k) return 0;
     const long long rows = (a.M + BM - 1) / BM;
-    if (a.N % 256 == 0 && rows * (a.N / 256) * a.batch >= min_tiles) return 256;
+    // the GELU' epilogue (backward pass) reads a second [M, N] operand per tile: with fewer than two full rounds of tiles the
+    // quantisation tail costs more than the main loop gains (M = 19200: 148 us against 115 for the 128 x 128 kernel)
+    const long long t256 = rows * (a.N / 256) * a.batch;
+    if (a.N % 256 == 0 && t256 >= (a.gelu_grad_of ? 2 * 232 : min_tiles)) return 256;
     const long long t128 = rows * (a.N / 128) * a.batch;
     if (on128 && a.N % 128 == 0 && t128 >= 150 && t128 <= 400) return 128;
     return 0;

@@ -260,8 +260,8 @@ def test_full_size_batch64_bf16_step_vs_oracle():
     assert worst[1] < 8e-2, worst
 
 
-def test_batch192_bf16_step_on_the_eight_phase_gemm_vs_oracle():
-    """A training step large enough for gemm_p8.hip to take the model's big products (batch 192: M = 19200 = 300 tiles of
+def test_batch384_bf16_step_on_the_eight_phase_gemm_vs_oracle():
+    """A training step large enough for gemm_p8.hip to take the model's big products (batch 384: M = 38400 = 600 tiles of
     256 x 256): its pre-activation copy (F, U), LayerNorm(64) + GELU and GELU' epilogues run in the forward and backward pass.
     Depth 2, G = 512 (the oracle's autograd on the CPU stays in seconds): predictions, loss and every gradient tensor against the
     fp32 oracle at the bf16 tolerances, and against the same step with the kernel switched off (the kernels it replaces)."""
@@ -271,7 +271,7 @@ def test_batch192_bf16_step_on_the_eight_phase_gemm_vs_oracle():
     lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
     cfg = dict(num_outputs=512, input_dim=1024, depth=2, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
     sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=17), seed=6)
-    B = 192
+    B = 384                     # 600 tiles: the GELU' epilogue is taken from two full rounds of tiles on
     x = torch.from_numpy(synth.cluster_tokens(5, B, 1024))
     y = torch.from_numpy(synth.rna_targets(8, B, 512))
     torch.set_num_threads(min(32, os.cpu_count()))
@@ -294,10 +294,11 @@ def test_batch192_bf16_step_on_the_eight_phase_gemm_vs_oracle():
     e_pred = rel_err(pred, pred_ref.detach().numpy())
     worst = max(((rel_err(gv[k], grads_ref[k].numpy()), k) for k in grads_ref), key=lambda t: t[0])
     worst_ab = max(((rel_err(gv[k], out[0][2][k]), k) for k in grads_ref), key=lambda t: t[0])
-    print(f"B=192 bf16 step on gemm_p8: pred rel err {e_pred:.3e}; loss {loss:.5f} vs {float(loss_ref):.5f}; worst gradient tensor vs oracle "
+    print(f"B=384 bf16 step on gemm_p8: pred rel err {e_pred:.3e}; loss {loss:.5f} vs {float(loss_ref):.5f}; worst gradient tensor vs oracle "
           f"{worst[0]:.3e} at {worst[1]}, vs the step without the kernel {worst_ab[0]:.3e} at {worst_ab[1]}")
     assert e_pred < 2e-2 and abs(loss - float(loss_ref)) < 2e-3 * float(loss_ref)
     assert worst[0] < 8e-2, worst
+    # (measured: bit-equal -- on gfx950 the 16x16x32 and 32x32x16 bf16 MFMAs evidently sum K in the same order; not relied upon)
     assert worst_ab[0] < 5e-2 and rel_err(pred, out[0][0]) < 1e-2
 
 
