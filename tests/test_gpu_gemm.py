@@ -198,7 +198,8 @@ def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched, bn):
     """gemm_p8.hip (256 x 256 x 64 tile, two buffers of four half-tiles, eight phases per pair of K-tiles, the two wave rows one
     barrier apart, 16x16x32 MFMAs), forced through the experiment knob: ragged M / N / K (an odd number of K-tiles, a K-tile
     with a single 16-byte chunk), bias, bf16 residual, ReLU / GELU, bf16 / fp32 output against the fp32 product of the same
-    bf16 operands and against the default tile (another MFMA shape sums K in another order: close, not bit-equal); run
+    bf16 operands and against the default tile -- BIT-EQUAL, although the MFMA shape differs (16x16x32 against 32x32x16: on gfx950 both evidently
+    accumulate K in the same order); run
     three times -- a schedule race would show as run-to-run differences.  Persistent form (one block per CU walking its tiles, the
     next tile's operands requested before the current tile's results are stored): the cases with more than 256 tiles."""
     _lib.require_gpu()
@@ -232,6 +233,9 @@ def test_eight_phase_256x256x64_variant(M, N, K, act, out, sched, bn):
     assert rel_err(outs[1].cpu(), ref.cpu()) < tol, rel_err(outs[1].cpu(), ref.cpu())
     assert rel_err(outs[1].cpu(), outs[0].cpu()) < tol
     assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
+    same = bool(torch.equal(outs[0], outs[1]))
+    print(f"gemm_p8 {M}x{N}x{K} act {act} {out} (sched {sched}, width {bn}): bit-equal to the default tile: {same}")
+    assert same, "gemm_p8 left the bits of the default tile (the 16x16x32 and 32x32x16 bf16 MFMAs sum K identically on gfx950: measured equal in every case)"
 
 
 @pytest.mark.parametrize("M,N,K", [(70000, 256, 1024), (65536 + 77, 128, 576)])

@@ -154,6 +154,42 @@ def test_config5_at_size_matches_literal_loop_on_probe_tiles(mode, tol):
     assert max(errs.values()) < tol, errs
 
 
+def test_config5_full_size_50k_tiles_probe_tiles_and_batch_invariance():
+    """BASELINE config 5 AS STATED: 50 000 tiles on a 250 x 200 grid, all valid -> 47 769 windows of 100 tokens at stride 1, the model
+    at its real size, bf16, 2048 windows per forward (what bench.py --workload spatial times).  (a) Probe tiles -- a corner (1
+    window), an edge and an interior tile (100 windows) -- against the literal per-window loop of visualize.py:35-102 over the
+    oracle model; (b) the whole [50 000, 20 820] result must not depend on how the windows are batched (2048 vs a ragged 700):
+    every window's rows go through the same arithmetic whatever its neighbours in the batch are."""
+    _lib.require_gpu()
+    nx, ny = 250, 200
+    xs, ys = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    df = pd.DataFrame({"xcoord_tf": xs.ravel(), "ycoord_tf": ys.ravel()})
+    feats = torch.randn(nx * ny, 1024, generator=torch.Generator().manual_seed(21))
+    cfg = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=22), seed=23)
+    m = ViS(**cfg, device="cuda:0", compute_dtype="bf16")
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    fd = feats.cuda()
+    out, votes = sliding_window_all_genes(df["xcoord_tf"].values, df["ycoord_tf"].values, fd, m, 1, batch_windows=2048)
+    assert out.shape == (nx * ny, 20820) and bool(torch.isfinite(out[votes > 0]).all())
+    assert int(votes.max()) == 100 and int((votes > 0).sum()) > 49000
+    at = lambda x, y: x * ny + y
+    probes = [at(0, 0), at(120, 0), at(131, 97)]
+    ref, n_windows = reference_loop_probe_tiles(df, feats, sd, probes)
+    errs = {k: rel_err(out[k].cpu().numpy(), ref[k]) for k in probes}
+    print(f"config 5 at FULL size (50 000 tiles), bf16: {n_windows} oracle windows for {len(probes)} probe tiles, votes {[int(votes[k]) for k in probes]}, "
+          f"worst rel err {max(errs.values()):.2e}")
+    assert int(votes[at(0, 0)]) == 1 and int(votes[at(131, 97)]) == 100
+    assert max(errs.values()) < 3e-2, errs
+    out2, votes2 = sliding_window_all_genes(df["xcoord_tf"].values, df["ycoord_tf"].values, fd, m, 1, batch_windows=700)
+    assert torch.equal(votes, votes2)
+    keep = votes > 0
+    diff = float((out[keep] - out2[keep]).abs().max() / out[keep].abs().max())
+    print(f"  2048 vs 700 windows per forward: max difference {diff:.2e} of max")
+    assert diff < 1e-5
+
+
 def test_visualize_cli_on_a_synthetic_slide(tmp_path):
     """spatial_vis/visualize.py:104-307 end to end: an in-memory 20x slide, mask -> valid tiles -> ResNet feature cache ->
     two-fold ViS ensemble and one HE2RNA fold -> stride-1 CSV; the CSV equals the library calls on the same cache."""
