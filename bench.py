@@ -311,7 +311,7 @@ def workload_pipeline(args, rank, world, device):
     cfg = dict(VIS_CFG, input_dim=1024 if uni else 2048)
     vis_dtype = "fp32" if args.dtype in ("bf16x3", "f16x3") else args.dtype      # the aggregator (0.2 % of the FLOP) stays exact fp32 in the split mode
     vis = ViS(**cfg, num_clusters=100, device=str(device), compute_dtype=vis_dtype).to(device).eval()
-    pipe = SlidePipeline(rn, vis, sub_batch=min(args.sub_batch, int(os.environ.get("SQ_BENCH_UNI_SUB_BATCH", "1000" if args.dtype == "bf16" else "256"))) if uni else args.sub_batch)
+    pipe = SlidePipeline(rn, vis, sub_batch=min(args.sub_batch, (args.uni_sub_batch or (1000 if args.dtype == "bf16" else 256))) if uni else args.sub_batch)
     # streaming form (default): the last slide's k-Means + ViS forward of a step run under the next step's first ResNet;
     # whatever is still in flight is flushed inside the timed region.  --no-stream: every step completes on its own.
     run = pipe if args.no_stream else pipe.submit
@@ -694,6 +694,8 @@ def main():
     ap.add_argument("--patches", type=int, default=1000, help="pipeline workload: patches per slide")
     ap.add_argument("--patch-size", type=int, default=224, help="pipeline workload: patch edge in pixels (224 = BASELINE config 3; 256 = the reference's default, patch_gen_hdf5.py:157)")
     ap.add_argument("--sub-batch", type=int, default=1000, help="pipeline workload: patches per ResNet launch group (two groups in flight)")
+    ap.add_argument("--uni-sub-batch", type=int, default=0, help="pipeline workload, UNI embedder: patches per launch group (default 1000 in bf16 "
+                    "-- 6.09 / 6.38 / 6.58 slides/s at 256 / 500 / 1000 -- and 256 in fp32: the 2 GiB descriptor limit)")
     ap.add_argument("--grid", type=int, nargs=2, default=[250, 200], help="spatial workload: tile grid")
     ap.add_argument("--batch-windows", type=int, default=2048, help="spatial workload: windows per ViS forward (2048: 452 ms per slide against 470 at 1024 and 505 at 512 -- more tiles per launch of the 256 x 256 GEMM)")
     ap.add_argument("--embedder", default="resnet", choices=["resnet", "uni"], help="pipeline workload: patch embedder")
@@ -776,6 +778,7 @@ def main():
                            ("pipeline_fp32_exact_mfma_mode", ["--workload", "pipeline", "--dtype", "fp32", "--slides", "2", "--sub-batch", "250", "--no-accuracy"]),
                            ("pipeline_256px_patches", ["--workload", "pipeline", "--patch-size", "256", "--slides", "4", "--no-accuracy"]),
                            ("vis_train_bf16", ["--workload", "vis_train"]),
+                           ("train_kfold_64_slides_per_gpu", ["--workload", "train_kfold"]),      # BASELINE config 4's per-GPU share on this one GPU
                            ("pipeline_uni_vit_l16_embedder", ["--workload", "pipeline", "--embedder", "uni", "--slides", "2"]),
                            ("spatial_50k_tiles", ["--workload", "spatial"])):
             cmd = [sys.executable, os.path.abspath(__file__), "--no-secondary", "--no-cpu-baseline", "--warmup", str(args.warmup)] + extra

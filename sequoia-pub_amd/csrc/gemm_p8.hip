@@ -8,23 +8,28 @@
 // makes every row a whole line with the operands left row-major, at the price of 128 KiB for TWO buffers; with two buffers
 // the load -> use distance comes from splitting the tile instead: a K-tile is four half-tiles (A even / odd 64-row groups,
 // B even / odd 32-column groups), each phase reads ONE half-tile's fragments, multiplies ONE 64 x 32 quadrant of the wave's
-// patch (16 MFMAs) and re-stages the half-tile that the previous phase read last -- so a slot is refilled one phase after
-// its last read and every request has six to seven phases (~2000 clocks) to land:
+// patch (16 MFMAs) and re-stages the half-tile whose last read lies TWO phases back -- so every request has six phases
+// (~2000 clocks) to land before the single counted wait of a K-tile:
 //
 //   phase  reads (ds_read_b128)         multiplies     stages (2 LDS-DMA instructions per thread)
-//   1      B_0 (4), A_0 (8) of tile t   A_0 x B_0      B_0 of tile t+1  (slot read last in phase 4 of tile t-1)
-//   2      B_1 (4)                      A_0 x B_1      A_0 of tile t+2
-//   3      A_1 (8)                      A_1 x B_1      B_1 of tile t+2
-//   4      B_0 (4)                      A_1 x B_0      A_1 of tile t+2;  s_waitcnt vmcnt(6): tile t+1 has landed
+//   1      B_0 (4), A_0 (8) of tile t   A_0 x B_0      A_1 of tile t+1  (slot read last in phase 3 of tile t-1)
+//   2      B_1 (4)                      A_0 x B_1      B_0 of tile t+1  (read last in phase 4 of tile t-1)
+//   3      A_1 (8)                      A_1 x B_1      A_0 of tile t+2  (read last in phase 1)
+//   4      B_0 (4)                      A_1 x B_0      B_1 of tile t+2  (read last in phase 2);  s_waitcnt vmcnt(4): tile t+1 has landed
 //
-// The two wave rows run ONE BARRIER apart (waves 4-7 take an extra s_barrier in front of the loop, waves 0-3 one behind
-// it): while one group of four waves -- one per SIMD -- issues its fragment reads and LDS-DMA, the other group's MFMAs own
-// the matrix pipes (s_setprio 1 around them), and vice versa.  Never a vmcnt(0) inside the loop; a wave's fragment reads are
-// retired (lgkmcnt(0)) before the barrier that lets the other group re-stage the slot.
+// The two groups of four waves (one wave of each per SIMD) run ONE BARRIER apart (waves 4-7 take an extra s_barrier in front
+// of the loop, waves 0-3 one behind it): while one group issues its fragment reads and LDS-DMA, the other group's MFMAs own
+// the matrix pipes (s_setprio 1 around them), and vice versa.  Never a vmcnt(0) inside the loop.  The fragments are waited for
+// BEHIND the phase barrier (their latency overlaps the barrier wait); that is safe because of the two-phase distance: a reader's
+// lgkmcnt(0) sits in front of its multiply, and the earliest re-stage of that slot by the other group comes a barrier later.
+// (Refilling one phase after the last read with the wait in front of the barrier -- three half-tiles in flight, vmcnt(6) --
+// measured the same, +-1 %.)
 // LDS image: 1 KiB sub-tiles of [16 rows][32 k], byte ^= ((byte >> 9) & 1) << 5 inside a sub-tile (rows 8-15 swap their
 // 32-byte halves): conflict-free 16-lane groups for the 16x16x32 fragment reads; with LDS-DMA the permutation sits on the
 // SOURCE address.  Half-tile A_a = block rows with (m >> 6) & 1 == a, B_b = columns with (n >> 5) & 1 == b, so that a wave's
 // 128 x 64 patch is contiguous in C although each of its quadrants lives in its own half-tile.
+// Tile walk: inside an XCD's contiguous run, 8 tile rows per group, column by column (kernel comment) -- operand panels stay in L2.
+// Results are bit-equal to the engine's 32x32x16 kernels (tests/test_gpu_gemm.py).
 // Epilogue: per-wave 16 x 64 fp32 slabs through LDS, 16-byte accesses; bias, residual, pre-activation copy, LayerNorm(64), ReLU / GELU,
 // GELU' multiply, bf16 copy -- every operand requested before the slab is written.
 // PERSISTENT form (one block per CU; block i of the 32 an XCD runs takes tiles i, i + 32, ... of the XCD's run): with K = 1024 a tile's
