@@ -382,13 +382,20 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                         for (int e = 0; e < 8; ++e) v[e] *= sq_gelu_grad<true>(gsrc[u][e]);
                     }
                 }
+                const u32x4 packed = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                 if (c32) {
                     float* d = c32 + (long long)m * p.ldc + e_n;
                     *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 }
-                const u32x4 packed = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                if (c16p) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = packed;
+                // non-temporal stores for bf16 results (SQ_GEMM_P8_NT=1): -5.5 % on 50432 x 4096 x 1024, -6 % on 102400 x 1024 x 1024 and -3 % on
+                // 8192^3 in the probe (tools/gemm_probe.py p8nt; fp32 results: level or slower) -- and NOTHING in the applications (UNI 6.81 vs
+                // 6.79 slides/s, spatial 447 vs 450 ms): there the next kernel re-reads the tensor, part of it from the caches the
+                // non-temporal store bypassed.  Off by default.
+                if (c16p) {
+                    if (!p.nt_bf16 || (DBG && (dbg & 32))) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = packed;
+                    else __builtin_nontemporal_store(packed, reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n));
+                }
                 if (p.C2) *reinterpret_cast<u32x4*>(p.C2 + (long long)z * p.sC2 + (long long)m * p.ldc2 + e_n) = packed;   // bf16 operand copy
             }
         };
@@ -518,6 +525,9 @@ int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
     if (env_persist < 0) { const char* e = getenv("SQ_GEMM_P8_PERSIST"); env_persist = e ? atoi(e) : 1; }
     if (env_skew == -2) { const char* e = getenv("SQ_GEMM_P8_SKEW"); env_skew = e ? atoi(e) : -1; }
     a.tile_group_m = g_p8_group_m > 0 ? g_p8_group_m : env_gm;
+    static int env_nt = -1;
+    if (env_nt < 0) { const char* e = getenv("SQ_GEMM_P8_NT"); env_nt = (e && e[0] == '1') ? 1 : 0; }          // opt-in: see the epilogue
+    a.nt_bf16 = env_nt;
     int bn = sq_gemm_p8_shape(a, SQ_BF16);
     if (g_p8_bn == 128 || g_p8_bn == 256) bn = g_p8_bn;         // probes / tests
     if (bn == 0) bn = 256;                                        // forced (tile 88) on a shape the heuristics would not pick

@@ -70,6 +70,12 @@ if __name__ == "__main__":
         for M, N, K in [(50432, 4096, 1024), (50432, 3072, 1024)]:           # bf16 output (what the UNI blocks write)
             probe(M, N, K, _lib.SQ_BF16, tiles=(55, 88), dbgs=(0,), out_bf16=True, scheds=(0, 1))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8nt":
+        # non-temporal result stores (dbg 16; dbg 32 = the same DBG build with plain stores, so that the two arms share one binary)
+        for out_bf16 in (False, True):
+            for M, N, K in [(50432, 4096, 1024), (50432, 1024, 1024), (102400, 1024, 1024), (8192, 8192, 8192)]:
+                probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(32, 16, 32, 16), scheds=(1,), out_bf16=out_bf16)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "p8m":
         # mid-size products: where does the 256 x 256 kernel (tile 88) start to beat the engine's pick (tile 0 = the kernel it replaces
         # below SQ_GEMM_P8_MIN_TILES tiles)?  tiles of 256 x 256 in brackets
