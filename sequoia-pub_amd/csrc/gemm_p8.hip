@@ -113,14 +113,14 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     const int G = PERSIST ? (int)(gridDim.x >> 3) : 1;
     int idx = blockIdx.x >> 3;
     if (idx >= run_count(xcd)) return;
-    int t_cur = run_start(xcd) + idx;
+    const int t_cur = run_start(xcd) + idx;
     if constexpr (PERSIST) {
         // experiment knob (tools/gemm_probe.py p8p): a start-up delay of (i mod 4) steps, to let the stores of some CUs run under
         // the K loops of others -- does not pay (launcher comment)
         if (p.skew_cycles > 0) {
             const long long t0 = __builtin_readcyclecounter();
             const long long wait = (long long)(idx & 3) * p.skew_cycles;
-            while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+            while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
         }
     }
     tile_coords(t_cur, m0, n0);
