@@ -117,9 +117,11 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     if constexpr (PERSIST) {
         // experiment knob (tools/gemm_probe.py p8p): a start-up delay of (i mod 4) steps, to let the stores of some CUs run under
         // the K loops of others -- does not pay (launcher comment)
-        if (p.skew_cycles > 0) {
+        if (p.skew_cycles != 0) {
             const long long t0 = __builtin_readcyclecounter();
-            const long long wait = (long long)(idx & 3) * p.skew_cycles;
+            // skew > 0: by block within the XCD (i mod 4 steps); skew < 0: by XCD parity (odd XCDs start |skew| cycles late: the blocks of an
+            // XCD stay in step and keep sharing operand panels in L2, the store bursts of the two halves of the chip alternate)
+            const long long wait = p.skew_cycles > 0 ? (long long)(idx & 3) * p.skew_cycles : (long long)(xcd & 1) * -(long long)p.skew_cycles;
             while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
         }
     }
@@ -537,7 +539,7 @@ int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
     if (persist && tiles > cus && cus >= 8) {
         // start-up skew (experiment knob, default none): measured SLOWER by more than the delay itself (50432 x 4096 x 1024: 454 us
         // in step, 527 us with a quarter-tile skew) -- blocks of an XCD that drift apart stop sharing operand panels in L2
-        a.skew_cycles = g_p8_skew >= 0 ? g_p8_skew : env_skew >= 0 ? env_skew : 0;
+        a.skew_cycles = g_p8_skew != -1 ? g_p8_skew : env_skew != -1 ? env_skew : 0;       // -1 = unset; other negatives: skew by XCD parity
         return bn == 256 ? launch_p8_pick<true, 256>(a, dim3(cus, 1, 1), stream) : launch_p8_pick<true, 128>(a, dim3(cus, 1, 1), stream);
     }
     return bn == 256 ? launch_p8_pick<false, 256>(a, dim3(tiles, 1, a.batch), stream) : launch_p8_pick<false, 128>(a, dim3(tiles, 1, a.batch), stream);

@@ -70,6 +70,16 @@ if __name__ == "__main__":
         for M, N, K in [(50432, 4096, 1024), (50432, 3072, 1024)]:           # bf16 output (what the UNI blocks write)
             probe(M, N, K, _lib.SQ_BF16, tiles=(55, 88), dbgs=(0,), out_bf16=True, scheds=(0, 1))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8x":
+        # start-up skew by XCD parity (negative knob values): odd XCDs start late, blocks of one XCD stay in step
+        for out_bf16 in (False, True):
+            for M, N, K in [(50432, 4096, 1024), (102400, 1024, 1024), (50432, 1024, 4096)]:
+                for skew in (0, -8000, -16000, -30000, -60000, 0):
+                    lib.sq_dbg_set(12, skew)
+                    print("xcd-parity skew", -skew, "bf16 out" if out_bf16 else "fp32 out")
+                    probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0,), scheds=(1,), out_bf16=out_bf16)
+        lib.sq_dbg_set(12, -1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "p8nt":
         # non-temporal result stores (dbg 16; dbg 32 = the same DBG build with plain stores, so that the two arms share one binary)
         for out_bf16 in (False, True):
