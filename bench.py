@@ -561,6 +561,7 @@ def accuracy_vs_reference(dtype_name, device, slides=("noise224",)):
     res = {"mode": dtype_name, "golden": "tests/golden/pipeline_slide*.npz (reference resnet50 + scikit-learn KMeans(100, random_state=0) + ViS, fp32 CPU)"}
     nets = {}
     for key in slides:
+        t_slide = time.perf_counter()
         fixture, make_patches, weights = GOLDEN_SLIDES[key]
         path = os.path.join(gdir, fixture)
         if not os.path.exists(path):
@@ -574,9 +575,21 @@ def accuracy_vs_reference(dtype_name, device, slides=("noise224",)):
             full.update(sd)
             rn.load_state_dict(full)
             nets[weights] = rn.to(device).eval()
+        t_net = time.perf_counter() - t_slide
         pipe = SlidePipeline(nets[weights], vis, n_clusters=100, sub_batch=500)
-        out = pipe([torch.from_numpy(make_patches()).to(device)])
+        t0 = time.perf_counter()
+        patches = torch.from_numpy(make_patches())
+        t_gen = time.perf_counter() - t0
+        if os.environ.get("SQ_BENCH_ACC_TRACE"):       # debugging aid: the stages one by one, synchronised
+            pd = patches.to(device)
+            for name, fn in (("upload sync", lambda: None), ("embed", lambda: pipe.embed(pd)), ("cluster", lambda: pipe.cluster(pipe.embed(pd).unsqueeze(0))),
+                             ("vis", lambda: vis(torch.zeros(1, 100, 2048, device=device)))):
+                t1 = time.perf_counter(); fn(); torch.cuda.synchronize()
+                print(f"accuracy trace {key}: {name} {time.perf_counter() - t1:.2f} s", file=sys.stderr, flush=True)
+        t0 = time.perf_counter()
+        out = pipe([patches.to(device)])
         torch.cuda.synchronize()
+        t_run = time.perf_counter() - t0
         feats = out["features"][0].cpu().numpy()
         labels = out["labels"][0].cpu().numpy().astype(np.int64)
         pred = out["pred"][0].cpu().numpy().astype(np.float64)
@@ -593,7 +606,9 @@ def accuracy_vs_reference(dtype_name, device, slides=("noise224",)):
                     "kmeans_n_iter_reference": int(z["n_iter"]),
                     "partition_rand_index": round(float(rand), 6),
                     "prediction_rel_err": float(f"{rel(pred, z['pred'].astype(np.float64)):.3e}"),
-                    "slides_rerun_in_fp32": int(getattr(pipe, "nonfinite_reruns", 0))}
+                    "slides_rerun_in_fp32": int(getattr(pipe, "nonfinite_reruns", 0)),
+                    "checker_seconds": {"weights": round(t_net, 1), "patches": round(t_gen, 1), "pipeline": round(t_run, 1),
+                                        "total": round(time.perf_counter() - t_slide, 1)}}
     return res
 
 

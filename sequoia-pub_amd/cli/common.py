@@ -23,9 +23,10 @@ def _parse_cpulist(text):
 
 
 def bind_to_gpu_numa_node(device_index):
-    """Pin this process's host threads to the CPUs of the NUMA node its GPU hangs off (PCI address -> sysfs numa_node ->
+    """Pin this process's launch (main) thread to the CPUs of the NUMA node its GPU hangs off (PCI address -> sysfs numa_node ->
     node cpulist -> sched_setaffinity).  On an 8-GPU node every rank then drives its GPU, and first-touches its pinned
-    staging buffers, from the local socket instead of wherever the launcher started it.  Never fails: returns a dict that
+    staging buffers, from the local socket instead of wherever the launcher started it; torch's intra-op pool is capped at 16
+    threads with it (see below).  Never fails: returns a dict that
     says what was done (bench.py prints it), or why nothing was."""
     info = {"gpu": int(device_index), "node": None, "cpus": None, "bound": False}
     try:
@@ -46,9 +47,16 @@ def bind_to_gpu_numa_node(device_index):
         if not cpus:
             info["why"] = "none of the node's CPUs is in this process's allowed set"
             return info
-        os.sched_setaffinity(0, cpus)
+        os.sched_setaffinity(0, cpus)           # (pid 0 = the calling thread; threads it starts later inherit the mask)
         info["cpus"] = len(cpus)
         info["bound"] = True
+        # Host-side glue (BN folding, plane splitting, index lists) is a stream of small torch ops; with the default pool of one thread
+        # per machine core they crawl once the launch thread is confined to a node -- spinning workers fight it for its CPUs: measured
+        # on a 2 x 128-CPU box, folding + splitting a ResNet-50: 23 s bound / 0.9 s unbound with the default pool, 0.1 s with 16
+        # threads either way (bench.py: 6.5 -> ~3 minutes).  Callers that time CPU work set their own thread count afterwards.
+        if torch.get_num_threads() > 16:
+            torch.set_num_threads(16)
+            info["torch_threads"] = 16
     except Exception as e:                      # sysfs layout, permissions, attribute names: never worth failing a run for
         info["why"] = f"{type(e).__name__}: {e}"
     return info

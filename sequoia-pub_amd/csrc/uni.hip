@@ -200,8 +200,12 @@ __global__ __launch_bounds__(256) void uni_attn_kernel(const T* __restrict__ qkv
 
 
 // ---- bf16 mode: the same attention on the matrix cores --------------------------------------------------------
-// One workgroup per (image, head); K [Tp][64] and V^T [64][Tp] of the head sit in LDS as bf16 (Tp = T rounded up to 32,
-// padded keys are masked).  A wave takes 32 queries at a time and computes everything TRANSPOSED so that a lane owns
+// One workgroup per (image, head); K [Tp][64] and V [Tp][64] of the head sit in LDS as bf16, both row-major with 16-byte
+// writes (Tp = T rounded up to 32, padded keys are masked).  V is consumed TRANSPOSED -- the A operand of O^T = V^T P^T wants 8
+// consecutive keys of one channel per lane -- through ds_read_b64_tr_b16: a 16-lane group hands the hardware [4 keys][16
+// channels] and every lane gets 4 consecutive keys of its channel (two reads = one 32x32x16 fragment).  Round 3 transposed
+// on the way INTO LDS with 2-byte stores (8 per 16 bytes loaded, neighbouring keys in the same dword): bank-serialised, it was
+// the bulk of the kernel's 21 us per workgroup (rocprofv3, round 4).  A wave takes 32 queries at a time and computes everything TRANSPOSED so that a lane owns
 // one query:   S^T = K Q^T  (A operand = K rows, B operand = the lane's query row, straight from global memory)
 //   -> lane (query q, half h) holds the scores of keys {32t + (r&3) + 8(r>>2) + 4h}: row max / sum are in-lane
 //      reductions plus ONE exchange with lane ^ 32; P = exp(S - max) is rounded to bf16 in registers;
@@ -210,7 +214,14 @@ __global__ __launch_bounds__(256) void uni_attn_kernel(const T* __restrict__ qkv
 //      the halves (cdna_hip_programming.md T12);
 //   -> lane holds 4 consecutive channels of ITS query per accumulator quad: scale by 1 / sum, pack, stage 32 x 64 bf16
 //      per wave in LDS, leave as 16-byte row-major stores.
-constexpr int VT_LD = 232;                // V^T row pitch in bf16 (464 B = 29 x 16 B: odd, ds_read_b128 conflict-free)
+typedef __bf16 uni_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 uni_lds_bf16x4;
+// ds_read_b64_tr_b16 (semantics as in gemm_tn.hip): within a 16-lane group, lane 4 j + c supplies the address of 4 contiguous bf16
+// (row j of four, columns 4 c .. 4 c + 3 of a 16-column block); lane i receives column i of rows 0 .. 3
+__device__ __forceinline__ u32x2 uni_tr_read(const char* p) {
+    const auto v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) uni_lds_bf16x4*)p);
+    return __builtin_bit_cast(u32x2, v);
+}
 
 __device__ __forceinline__ f32x16 mma_bf16(const u32x4& a, const u32x4& b, f32x16 acc) {
     union { u32x4 u; bf16x8 h; } ua, ub;
@@ -222,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void uni_attn_mfma_kernel(const bf16_t* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntile = (Ttok + 31) / 32, Tp = ntile * 32;
     char* sK = smem;                                   // [Tp][128 B], 16-byte chunks swizzled by (row >> 1) & 7
-    bf16_t* sVt = reinterpret_cast<bf16_t*>(smem + 256 * 128);        // [64][VT_LD]
-    char* sO = smem + 256 * 128 + 64 * VT_LD * 2;      // [4 waves][32 q][128 B]
+    char* sV = smem + 256 * 128;                       // [Tp][128 B], the same chunk swizzle
+    char* sO = smem + 2 * 256 * 128;                   // [4 waves][32 q][128 B]
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int I = H * DH, ldq = 3 * I;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -237,12 +248,13 @@ __global__ __launch_bounds__(256, 2) void uni_attn_mfma_kernel(const bf16_t* __r
             vv = *reinterpret_cast<const u32x4*>(base + (size_t)r * ldq + 2 * I + c * 8);
         }
         *reinterpret_cast<u32x4*>(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sVt[(c * 8 + 2 * e) * VT_LD + r] = (bf16_t)(vv[e] & 0xffffu);
-            sVt[(c * 8 + 2 * e + 1) * VT_LD + r] = (bf16_t)(vv[e] >> 16);
-        }
+        *reinterpret_cast<u32x4*>(sV + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = vv;
     }
+    // transposing-read geometry of this lane: group G = lane >> 4 serves channels (G & 1) * 16 .. + 16 and the keys of k half G >> 1;
+    // as a supplier the lane hands over key offset j = (lane >> 2) & 3, channels 4 (lane & 3) .. + 3 of that block
+    const int tr_j = (lane >> 2) & 3, tr_c = lane & 3, tr_G = lane >> 4;
+    const int tr_chunk0 = (tr_G & 1) * 2 + (tr_c >> 1);          // 16-byte chunk of the row (+ 4 nt), before the swizzle
+    const int tr_sub = (tr_c & 1) << 3;                          // byte inside the chunk
     __syncthreads();
     char* myO = sO + wave * 4096;
     for (int qb = wave; qb < ntile; qb += 4) {
@@ -307,10 +319,15 @@ __global__ __launch_bounds__(256, 2) void uni_attn_mfma_kernel(const bf16_t* __r
                     auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
                     auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
                     const u32x4 pf = {(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};      // keys base + 8*lh .. +7
-                    const int kb = t * 32 + hf * 16 + lh * 8;
+                    const int key0 = t * 32 + hf * 16 + (tr_G >> 1) * 8 + tr_j;          // this lane's supplied key (first read; + 4 second)
+                    const int key1 = key0 + 4;
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        ot[nt] = mma_bf16(*reinterpret_cast<const u32x4*>(sVt + (nt * 32 + l31) * VT_LD + kb), pf, ot[nt]);
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int ch = nt * 4 + tr_chunk0;
+                        const u32x2 v0 = uni_tr_read(sV + key0 * 128 + ((ch ^ ((key0 >> 1) & 7)) << 4) + tr_sub);
+                        const u32x2 v1 = uni_tr_read(sV + key1 * 128 + ((ch ^ ((key1 >> 1) & 7)) << 4) + tr_sub);
+                        ot[nt] = mma_bf16(u32x4{v0[0], v0[1], v1[0], v1[1]}, pf, ot[nt]);     // lane: channel nt*32 + l31, keys kb .. kb + 7
+                    }
                 }
             }
         // lane = query l31, channels nt*32 + 8g + 4lh .. +3  ->  staging row l31
@@ -457,8 +474,8 @@ extern "C" int sq_uni_forward(const sq_uni_config* c, int dtype, const float* pa
     SQ_LAUNCH_CHECK();
 
     const size_t att_lds = ((size_t)T * DH * 2 + (size_t)T * (DH + 1) + 4 * ATT_MAXT) * sizeof(float);
-    const size_t att_mfma_lds = 256 * 128 + 64 * VT_LD * 2 + 4 * 4096;
-    const bool valu_attn = sq_env_flag("SQ_UNI_VALU_ATTN") || (T + 31) / 32 * 32 > VT_LD - 8;   // A/B knob; V^T rows hold <= 224 keys
+    const size_t att_mfma_lds = 2 * 256 * 128 + 4 * 4096;
+    const bool valu_attn = sq_env_flag("SQ_UNI_VALU_ATTN") || (T + 31) / 32 * 32 > 256;   // A/B knob; the K / V images hold <= 256 keys
     static SqDevOnce attr;       // hipFuncSetAttribute is per device
     if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)uni_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_mfma_lds));
