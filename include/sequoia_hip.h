@@ -285,6 +285,12 @@ int sq_linear_x3(int fmt, const void* A_hi, const void* A_lo, int lda, const voi
  * workspace: optional fp32 scratch enabling deterministic split-K over the tokens. */
 int sq_linear_weight_grad(int dtype, const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, float* dbias,
                           int n_out, int n_in, int n_tokens, void* workspace, size_t workspace_bytes, sq_stream_t stream);
+/* The same for up to FOUR same-shape layers in ONE launch (host arrays of device pointers; dbias: NULL, or one pointer per member):
+ * the weight gradients of a transformer layer's linear maps (src/tformer_lin.py:18-26,54-57 under `loss.backward()`, src/vit.py:178) are
+ * independent products whose 128 x 128 tile grids fill a quarter of the chip each -- together they fill it without slicing the tokens.
+ * bf16 members whose extents are multiples of 128 run on the four-stage ring form of the kernel (csrc/gemm_tn.hip). */
+int sq_linear_weight_grad_group(int dtype, int n_members, const void* const* dY, const void* const* X, float* const* dW,
+                                float* const* dbias, int lddy, int ldx, int lddw, int n_out, int n_in, int n_tokens, sq_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * UNI patch embedder: timm ``vit_large_patch16_224`` with ``init_values=1e-5, num_classes=0`` as

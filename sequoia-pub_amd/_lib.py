@@ -151,6 +151,8 @@ def _declare(lib):
     lib.sq_he2rna_topk_mean_bwd.argtypes = [vp, i32, vp, vp, i32, f32, vp, vp, i32, i32, i32, i32, vp]
     lib.sq_linear_weight_grad.restype = i32
     lib.sq_linear_weight_grad.argtypes = [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, sz, vp]
+    lib.sq_linear_weight_grad_group.restype = i32
+    lib.sq_linear_weight_grad_group.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.sq_linear_x3.restype = i32
     lib.sq_linear_x3.argtypes = [i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.sq_cast_f32_to_bf16.restype = i32

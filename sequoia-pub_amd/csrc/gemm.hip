@@ -523,7 +523,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 int g_force_tile = 0, g_force_split = 0, g_use256 = -1, g_use_ring = -1;
 }
 int g_dbg = 0;                   // shared with gemm_x3.hip
-extern int g_tn_force_split;
+extern int g_tn_force_split, g_tn_ring;
 namespace {
 
 template <typename T>
@@ -592,6 +592,7 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 5) g_use256 = value;
     else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
+    else if (key == 15) g_tn_ring = value;            // gemm_tn.hip: ring form on / off (-1: environment)
     else if (key == 7) g_x3_small_max_k = value;
     else if (key == 14) g_p8_on = value;             // gemm_p8.hip on / off (-1: environment)
     else if (key == 13) g_p8_bn = value;             // gemm_p8.hip: forced tile width (128 / 256)

@@ -16,6 +16,7 @@
 #include "gemm_epi.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -36,6 +37,14 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
     bf16x4 r;
     r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3];
     return r;
+}
+
+// the same read as inline assembly (ring form below): LDS byte address + immediate offset
+template <int OFF>
+__device__ __forceinline__ u32x2 tr_read_asm(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
 }
 
 template <typename T>
@@ -288,9 +297,275 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ring form (bf16, both output extents multiples of 128): what the large weight gradients of a training step run on.
+//
+// The two-buffer kernel above keeps ONE K-step in flight: with a single 4-wave block per CU (256 tiles of a grouped
+// launch = one per CU) every step exposes the full L2 / HBM round trip in front of its 32 MFMAs -- 1.0 us per 64-row step,
+// 135 us for the four 1024 x 1024 x 6400 gradients of a layer (398 TF).  Here:
+//   * eight waves per 128 x 128 tile: waves 0-3 and 4-7 each hold the whole 2 x 2 arrangement of 64 x 64 patches and take
+//     rows 0-31 / 32-63 of every 64-row step (an in-block K split: two waves per SIMD, one's transposing LDS reads run under
+//     the other's MFMAs; the two accumulator sets are added through LDS in the epilogue, fixed order);
+//   * FOUR stages of 32 KiB (A rows + B rows, token-major as stored), three steps in flight, one counted
+//     `s_waitcnt vmcnt(8)` per step; steps beyond the slice's end are issued out of range (the buffer descriptor returns
+//     zeros), so the count is the same in every iteration; two raw `s_barrier`s per step with the two wave sets half a step
+//     apart (one issues its LDS-DMA requests while the other reads fragments and multiplies -- see "Schedule" in the kernel);
+//   * tile walk: XCD x (blocks x, x + 8, ...) owns a contiguous run of the work list, and the list is ordered in 8 x 4
+//     patches of tiles -- the 32 blocks resident on an XCD read 8 A strips + 4 B strips (12 x 1.6 MB for K = 6400) instead
+//     of 4 x (4 + 2) = 24;
+//   * the bias gradient (column sums of A) rides in the tiles themselves: the 128 columns of a tile row are eight 16-wide
+//     fragment blocks, block s is summed by tile column s % tiles_n with one extra MFMA (fragment x ones) per step in two of
+//     its eight waves -- no extra blocks in the grid.
+constexpr int RG_BT = 128, RG_ROWB = 256, RG_KR = 64, RG_TILE = RG_KR * RG_ROWB, RG_STAGE = 2 * RG_TILE, RG_NST = 4;
+constexpr int RG_SLD = RG_BT + 4;                         // fp32 stage row pitch (floats)
+constexpr int RG_LDS = RG_NST * RG_STAGE;                 // 128 KiB (the epilogue's 128 x 132 fp32 stage + column sums fit inside)
+
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs p, const int tiles_m, const int tiles_n, const int total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+
+    // work item of this block: XCD-contiguous runs of the list [member][slice][patch of 8 x 4 tiles][tile]
+    const int per = (total + 7) >> 3;
+    const int L = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (L >= total) return;
+    const int tpm = tiles_m * tiles_n;
+    const int zs = L / tpm, r = L - zs * tpm;
+    const int z = zs / p.splitk, slice = zs - z * p.splitk;
+    int mt, nt;
+    if ((tiles_m & 7) == 0 && (tiles_n & 3) == 0) {
+        const int patch = r >> 5, q = r & 31, pn = tiles_n >> 2;
+        mt = (patch / pn) * 8 + (q >> 2);
+        nt = (patch % pn) * 4 + (q & 3);
+    } else {
+        mt = r / tiles_n;
+        nt = r - mt * tiles_n;
+    }
+    const int m0 = mt * RG_BT, n0 = nt * RG_BT;
+
+    const bool grouped = p.ngroup > 0;
+    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(grouped ? sq_group_pick(p.gA, z) : p.A);
+    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(grouped ? sq_group_pick(p.gB, z) : p.B);
+    float* const colsum_dst = grouped ? sq_group_pick(p.gcs, z) : p.colsum_a;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)p.b_bytes, 0x00020000);
+
+    const int nk_all = (p.K + RG_KR - 1) / RG_KR;
+    const int per_k = (nk_all + p.splitk - 1) / p.splitk;
+    const int kt_lo = slice * per_k, kt_hi = min(nk_all, kt_lo + per_k);
+    const int nk = max(kt_hi - kt_lo, 0);
+
+    // DMA lane mapping: a wave instruction fills 4 rows of 256 B; instruction j of wave w -> rows (8j + w) * 4 ..+3
+    const int lrow = lane >> 4, lchunk = lane & 15;
+    auto key = [](int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; };
+    uint32_t src_a[2], src_b[2];      // byte offset of this lane's 16 bytes inside a step (row part), per instruction
+    int row_j[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 8 + wave) * 4 + lrow;
+        const int gchunk = lchunk ^ key(row);
+        row_j[j] = row;
+        src_a[j] = (uint32_t)(((long long)row * p.lda + m0 + gchunk * 8) * 2);
+        src_b[j] = (uint32_t)(((long long)row * p.ldb + n0 + gchunk * 8) * 2);
+    }
+    const uint32_t step_a = (uint32_t)p.lda * RG_KR * 2, step_b = (uint32_t)p.ldb * RG_KR * 2;
+    auto issue = [&](int kt, int buf) {
+        char* sa = smem + buf * RG_STAGE;
+        char* sb = sa + RG_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = kt < kt_hi && kt * RG_KR + row_j[j] < p.K;
+            const uint32_t oa = ok ? src_a[j] + (uint32_t)kt * step_a : OOB;
+            const uint32_t ob = ok ? src_b[j] + (uint32_t)kt * step_b : OOB;
+            glds16(rsA, sa + (j * 8 + wave) * 4 * RG_ROWB, oa, 0);
+            glds16(rsB, sb + (j * 8 + wave) * 4 * RG_ROWB, ob, 0);
+        }
+    };
+
+    // transposing fragment reads (as in the kernel above); this wave's rows of a step start at 32 * kg
+    const int li = lane & 15, lg = lane >> 4;
+    int tr_a[4], tr_b[4];
+    {
+        const int j = (lane >> 2) & 3, c = lane & 3;
+        const int row = 8 * lg + j, kx = key(row);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int qa = wm * 8 + 2 * t + (c >> 1), qb = wn * 8 + 2 * t + (c >> 1);
+            tr_a[t] = (kg * 32 + row) * RG_ROWB + ((qa ^ kx) << 4) + ((c & 1) << 3);
+            tr_b[t] = (kg * 32 + row) * RG_ROWB + ((qb ^ kx) << 4) + ((c & 1) << 3);
+        }
+    }
+    // column sums: fragment block s = wm * 4 + t of this tile row belongs to tile column s % tiles_n
+    int csmask = 0;
+    if (colsum_dst && wn == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if ((wm * 4 + t) % tiles_n == nt) csmask |= 1 << t;
+    }
+    csmask = __builtin_amdgcn_readfirstlane(csmask);
+
+    f32x4 acc[4][4], cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    // The fragment reads are inline assembly: hipcc treats the transposing-read BUILTIN as possibly aliasing the LDS-DMA
+    // requests in flight and puts `s_waitcnt vmcnt(0)` in front of it -- which would drain the ring every step.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // Schedule.  Per step a CU stages 32 KiB through its vector-memory path (64 B/clk: 512 cycles -- and a wave that is issuing
+    // LDS-DMA requests issues nothing else meanwhile), reads 64 KiB of fragments (256 LDS cycles) and runs 512 cycles of MFMAs
+    // per SIMD; a block-wide barrier costs ~165 cycles.  Measured with ablation switches (tools/tn_probe.py abl): when every wave
+    // does request -> read -> multiply in order the three costs ADD (1560 cycles per step); with two barriers per step and the
+    // wave sets half a step apart a phase is max(request + read, multiply) + barrier (1240 cycles).  What runs: ONE barrier per
+    // step; behind it waves 0-3 issue their requests FIRST and waves 4-7 LAST, so that on every SIMD (waves w and w + 4 share one)
+    // one wave sits in the memory path while the other owns the matrix pipe; the fragment reads of step `it` are issued ahead of
+    // the MFMAs of step it-1 (two register sets) and waited for behind them, when they have long returned.
+    typedef u32x2 frag_set[4][2];
+    frag_set ra0, rb0, ra1, rb1;       // fragments of two consecutive steps (set = step parity; separate objects: no run-time indexing)
+    const int dbg = p.dbg;             // ablation switches (tools/tn_probe.py abl): 2 no requests after the prologue, 4 no MFMA
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ra0[t][h] = rb0[t][h] = ra1[t][h] = rb1[t][h] = u32x2{0u, 0u};
+    auto read_frags = [&](int buf, frag_set& ra, frag_set& rb) {
+        const uint32_t sbase = lds0 + (uint32_t)buf * RG_STAGE;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ra[t][0] = tr_read_asm<0>(sbase + tr_a[t]); ra[t][1] = tr_read_asm<4 * RG_ROWB>(sbase + tr_a[t]);
+            rb[t][0] = tr_read_asm<RG_TILE>(sbase + tr_b[t]); rb[t][1] = tr_read_asm<RG_TILE + 4 * RG_ROWB>(sbase + tr_b[t]);
+        }
+    };
+    auto frags_landed = [&](frag_set& ra, frag_set& rb) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]), "+v"(ra[3][0]), "+v"(ra[3][1]) :: "memory");
+        asm volatile("" : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1]) :: "memory");
+    };
+    auto multiply = [&](const frag_set& ra, const frag_set& rb) {
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32x4 ua = {ra[t][0][0], ra[t][0][1], ra[t][1][0], ra[t][1][1]}, ub = {rb[t][0][0], rb[t][0][1], rb[t][1][0], rb[t][1][1]};
+            fa[t] = __builtin_bit_cast(bf16x8, ua);
+            fb[t] = __builtin_bit_cast(bf16x8, ub);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (csmask) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (csmask & (1 << t)) cs[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t], ones, cs[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto request = [&](int it) {
+        if (!(dbg & 2)) issue(kt_lo + it + RG_NST - 1, (it + RG_NST - 1) & (RG_NST - 1));
+    };
+    // one step: its fragments go to (ra, rb); the previous step's are in (pa, pb)
+    auto step = [&](int it, frag_set& ra, frag_set& rb, const frag_set& pa, const frag_set& pb) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // this wave's requests of step `it` have landed (two later steps x 4 may be out)
+        __builtin_amdgcn_s_barrier();                           // everybody's; and step it-1's buffer has been read by every wave
+        if (kg == 0) request(it);                               // waves 0-3 sit in the memory path first ...
+        read_frags(it & (RG_NST - 1), ra, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it > 0 && !(dbg & 4)) multiply(pa, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        frags_landed(ra, rb);                                   // (in front of the next barrier: behind it the buffer may be refilled)
+        if (kg != 0) request(it);                               // ... waves 4-7 last, under the others' MFMAs
+    };
+
+#pragma unroll
+    for (int s = 0; s < RG_NST - 1; ++s) issue(kt_lo + s, s);
+    for (int it = 0; it < nk; it += 2) {
+        step(it, ra0, rb0, ra1, rb1);
+        if (it + 1 < nk) step(it + 1, ra1, rb1, ra0, rb0);
+    }
+    if (nk > 0 && !(dbg & 4)) {
+        if ((nk - 1) & 1) multiply(ra1, rb1); else multiply(ra0, rb0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (out-of-range requests still write zeros: none may land in the stage below)
+    __syncthreads();
+
+    // ---- epilogue: waves 4-7 park their sums in LDS, waves 0-3 add theirs on top (16x16 C/D layout: col = lane&15, row = 4*(lane>>4) + reg)
+    float* stage = reinterpret_cast<float*>(smem);
+    float* cstage = stage + RG_BT * RG_SLD;                     // [128] column sums of the other K half
+    if (kg == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) stage[(wm * 64 + i * 16 + lg * 4 + rr) * RG_SLD + wn * 64 + j * 16 + li] = acc[i][j][rr];
+        if (csmask && li == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (csmask & (1 << t))
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) cstage[wm * 64 + t * 16 + lg * 4 + rr] = cs[t][rr];
+        }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    float* q = stage + (wm * 64 + i * 16 + lg * 4 + rr) * RG_SLD + wn * 64 + j * 16 + li;
+                    *q = acc[i][j][rr] + *q;
+                }
+        if (csmask && li == 0) {
+            float* dst = p.splitk > 1 ? p.splitk_ws + (size_t)p.batch * p.splitk * (size_t)p.M * p.N + ((size_t)z * p.splitk + slice) * p.M : colsum_dst;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (csmask & (1 << t))
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int ml = wm * 64 + t * 16 + lg * 4 + rr;
+                        dst[m0 + ml] = cs[t][rr] + cstage[ml];
+                    }
+        }
+    }
+    __syncthreads();
+    const int c8 = tid & 15, rbase = tid >> 4;                  // 32 rows x 16 chunks of 8 columns per pass
+    const int n = n0 + c8 * 8;
+    if (p.splitk > 1) {
+        float* part = p.splitk_ws + ((size_t)z * p.splitk + slice) * (size_t)p.M * p.N;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = rbase + u * 32, m = m0 + row;
+            *reinterpret_cast<f32x4*>(part + (size_t)m * p.N + n) = *reinterpret_cast<const f32x4*>(stage + row * RG_SLD + c8 * 8);
+            *reinterpret_cast<f32x4*>(part + (size_t)m * p.N + n + 4) = *reinterpret_cast<const f32x4*>(stage + row * RG_SLD + c8 * 8 + 4);
+        }
+        return;
+    }
+    const bool vec = p.vec_epi != 0;
+    void* const c_ovr = grouped ? sq_group_pick(p.gC, z) : nullptr;
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {
+        const int row = rbase + u * 32, m = m0 + row;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + row * RG_SLD + c8 * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(stage + row * RG_SLD + c8 * 8 + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        epi_apply<3>(p, 0, m, n, v, 8, vec, nullptr, nullptr, c_ovr);
+    }
+}
+
 }  // namespace
 
 int g_tn_force_split = 0;      // experiment knob (sq_dbg_set key 4)
+extern int g_dbg;               // sq_dbg_set key 1 (gemm.hip)
+int g_tn_ring = -1;            // sq_dbg_set key 15 (tests / probes): 0 / 1 overrides SQ_GEMM_TN_RING
 
 int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
     GemmArgs a = a_in;
@@ -330,6 +605,40 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
     const int nk = (a.K + kr - 1) / kr;
     const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     a.splitk = 1;
+    // large bf16 gradients: the four-stage ring form (one 8-wave block per CU); SQ_GEMM_TN_RING=0 / sq_dbg_set(15, 0) turns it off
+    if (g_tn_ring < 0) { const char* e = getenv("SQ_GEMM_TN_RING"); g_tn_ring = (e && e[0] == '0') ? 0 : 1; }
+    if (g_tn_ring && dtype == SQ_BF16 && a.M % 128 == 0 && a.N % 128 == 0 && (a.batch == 1 || a.ngroup) && nk >= 8 &&
+        tiles * a.batch >= 8) {
+        const long long work = tiles * a.batch;
+        const size_t per_slice = ((size_t)a.M * a.N * a.batch + (a.colsum_a ? (size_t)a.M * a.batch : 0)) * sizeof(float);
+        if (a.splitk_ws && work < 256) {
+            long long s = 256 / work;                          // one round of blocks, one block per CU
+            if (s > nk / 8) s = nk / 8;
+            while (s > 1 && (size_t)s * per_slice > a.splitk_ws_bytes) --s;
+            if (s > 1) a.splitk = (int)s;
+        }
+        if (g_tn_force_split > 0 && a.splitk_ws && (size_t)g_tn_force_split * per_slice <= a.splitk_ws_bytes) a.splitk = g_tn_force_split;
+        static SqDevOnce attr;
+        if (attr.needed()) {
+            SQ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS));
+            attr.done();
+        }
+        int prof = -1;
+        if (sq_prof_on()) {
+            char name[96];
+            snprintf(name, sizeof(name), "gemmtn_bf16_M%d_N%d_K%d_b%d", a.M, a.N, a.K, a.batch);
+            prof = sq_prof_begin(name, 2.0 * a.M * (double)a.N * a.K * a.batch, ((double)a.K * (a.M + a.N) * 2.0 + (double)a.M * a.N * 4.0) * a.batch, stream);
+        }
+        const int total = (int)(work * a.splitk);
+        a.dbg |= g_dbg;
+        const dim3 grid((unsigned)((total + 7) / 8 * 8)), block(512);
+        hipLaunchKernelGGL(gemm_tn_ring_kernel, grid, block, RG_LDS, stream, a, a.M / 128, a.N / 128, total);
+        SQ_LAUNCH_CHECK();
+        int rc = SQ_OK;
+        if (a.splitk > 1) rc = sq_launch_splitk_reduce(a, stream);
+        if (prof >= 0) sq_prof_end(prof, stream);
+        return rc;
+    }
     const long long cs_blocks = a.colsum_a ? ((a.M + 127) / 128 + 7) / 8 * 8 : 0;
     if (a.splitk_ws && tiles * a.batch < 256 && nk >= 4) {
         // 2 blocks (64 KiB LDS each) per CU x 256 CUs: the whole grid should be resident at once

@@ -296,3 +296,20 @@ extern "C" int sq_linear_weight_grad(int dtype, const void* dY, int lddy, const 
     g.splitk_ws = (float*)workspace; g.splitk_ws_bytes = workspace_bytes;
     return sq_launch_gemm_tn(g, dtype, (hipStream_t)stream);
 }
+
+extern "C" int sq_linear_weight_grad_group(int dtype, int n_members, const void* const* dY, const void* const* X, float* const* dW,
+                                           float* const* dbias, int lddy, int ldx, int lddw, int n_out, int n_in, int n_tokens,
+                                           sq_stream_t stream) {
+    SQ_REQUIRE(dY && X && dW && n_members >= 1 && n_members <= 4, "linear_weight_grad_group: 1..4 members (got %d)", n_members);
+    GemmArgs g;
+    const size_t es = sq_dtype_size(dtype);
+    g.lda = lddy; g.a_bytes = (size_t)n_tokens * lddy * es;
+    g.ldb = ldx; g.b_bytes = (size_t)n_tokens * ldx * es;
+    g.ldc = lddw; g.M = n_out; g.N = n_in; g.K = n_tokens;
+    g.ngroup = n_members;
+    for (int i = 0; i < n_members; ++i) {
+        g.gA[i] = dY[i]; g.gB[i] = X[i]; g.gC[i] = dW[i];
+        g.gcs[i] = dbias ? dbias[i] : nullptr;
+    }
+    return sq_launch_gemm_tn(g, dtype, (hipStream_t)stream);
+}

@@ -122,6 +122,48 @@ def test_weight_grad_tn_kernel(T, NO, NI, dtype, ws_bytes):
     assert rel_err(dW2.cpu(), dW.cpu()) < 1e-6          # (the K-slice count, hence the summation order, may differ)
 
 
+@pytest.mark.parametrize("T,NO,NI,members", [(6400, 1024, 1024, 4), (6390, 1024, 1024, 1), (777, 256, 384, 3), (1500, 512, 2048, 2), (520, 128, 256, 4)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_weight_grad_group_ring_form(T, NO, NI, members, with_bias):
+    """Up to four same-shape weight gradients in one launch (sq_linear_weight_grad_group): the four-stage ring form of the TN
+    kernel (bf16, extents multiples of 128: 8 waves per tile with an in-block K split, XCD-contiguous tile walk, bias gradient
+    inside the tiles) against fp64, against the two-buffer kernel, ragged token counts, and bitwise repeatable."""
+    _lib.require_gpu()
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(T + NO + NI + members)
+    dYs = [to_bf16_f32(torch.randn(T, NO, generator=g) + 0.05 * i) for i in range(members)]
+    Xs = [to_bf16_f32(torch.randn(T, NI, generator=g) + torch.arange(NI)[None, :] * 1e-3) for i in range(members)]
+    dYd = [t.to("cuda", torch.bfloat16).contiguous() for t in dYs]
+    Xd = [t.to("cuda", torch.bfloat16).contiguous() for t in Xs]
+
+    def run(ring):
+        lib.sq_dbg_set(15, ring)
+        try:
+            dW = [torch.full((NO, NI), float("nan"), device="cuda") for _ in range(members)]
+            db = [torch.full((NO,), float("nan"), device="cuda") for _ in range(members)]
+            arr = lambda ts: (ctypes.c_void_p * members)(*[t.data_ptr() for t in ts])
+            _lib.check(lib.sq_linear_weight_grad_group(_lib.SQ_BF16, members, arr(dYd), arr(Xd), arr(dW), arr(db) if with_bias else None,
+                                                       NO, NI, NI, NO, NI, T, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+        finally:
+            lib.sq_dbg_set(15, -1)
+        return [w.cpu() for w in dW], [b.cpu() for b in db]
+
+    dW1, db1 = run(1)
+    dW1b, db1b = run(1)
+    dW0, db0 = run(0)
+    for i in range(members):
+        ref = dYs[i].double().T @ Xs[i].double()
+        assert rel_err(dW1[i], ref) < 1e-5, (i, rel_err(dW1[i], ref))
+        assert rel_err(dW0[i], ref) < 1e-5, (i, rel_err(dW0[i], ref))
+        assert torch.equal(dW1[i], dW1b[i])
+        if with_bias:
+            rb = dYs[i].double().sum(0)
+            assert rel_err(db1[i], rb) < 1e-5, (i, rel_err(db1[i], rb))
+            assert rel_err(db0[i], rb) < 1e-5
+            assert torch.equal(db1[i], db1b[i])
+
+
 def test_bad_arguments_fail_loudly():
     _lib.require_gpu()
     A = torch.zeros(4, 6, device="cuda")
