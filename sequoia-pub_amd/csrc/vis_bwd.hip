@@ -34,7 +34,7 @@ struct BwdBufs {
     LayerG lg[SQ_MAX_DEPTH];
     float* dY;                       // [M, D] f32
     float* dLf;                      // [M, HD] f32
-    void* whT;                       // [D, Gp] T   transposed weights, all produced by one launch up front
+    void* doutT;                     // [Gp, Bp] T  d(loss)/d(out) transposed (gene-major): the head's dX product contracts over genes
     struct LayerT { void *ff2, *ff1, *proj, *wc_lf, *wc_ts, *s, *f; } wt[SQ_MAX_DEPTH];
     float* dCs; float* dTs; float* dXbar;   // [B, HD] / [B, D]
     void* dout_lp;                   // [B, Gp] T
@@ -74,7 +74,7 @@ void bwd_bufs(const sq_vis_config& c, int dtype, int B, char* base, BwdBufs* o) 
             g = o->lg[0];
         }
     }
-    o->whT = a.take(D * Gp * es);
+    o->doutT = a.take(Gp * sq_align_up((size_t)B, 8) * es);
     for (int l = 0; l < c.depth; ++l) {
         o->wt[l].ff2 = a.take(D * D * es); o->wt[l].ff1 = a.take(D * D * es);
         o->wt[l].proj = a.take(HD * D * es);
@@ -157,7 +157,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
     }
     const int N = c->num_clusters, D = c->input_dim, H = c->nheads, HD = H * SQ_HEAD_DIM, G = c->num_outputs;
     const int M = B * N;
-    const int Gp = (int)sq_align_up(G, 8);
+    const int Gp = (int)sq_align_up(G, 8), Bp = (int)sq_align_up((size_t)B, 8);
     const int es = sq_dtype_size(dtype);
     const bool lp = dtype == SQ_BF16;
     const char* wbase = lp ? (const char*)params_lp : (const char*)params;
@@ -185,7 +185,8 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         return g;
     };
 #define RUN(expr) do { if (int _e = (expr)) return _e; } while (0)
-    {   // every "dX = dY . W" below is an NT product on W^T: transpose all weights with one launch
+    RUN(sq_k_cast_pad(grad_out, G, b.dout_lp, dtype, Gp, B, G, st));
+    {   // every layer's "dX = dY . W" below is an NT product on W^T: transpose those weights with one launch
         sq_transpose_jobs jobs;
         auto add = [&](const void* src, int lds_, void* dst, int ldd, int R, int C, int batch, long long ss, long long ds) {
             if (jobs.n == SQ_MAX_TRANSPOSE_JOBS) {               // deeper models than one argument block holds
@@ -195,7 +196,9 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
             return sq_transpose_jobs_add(&jobs, src, lds_, dst, ldd, R, C, batch, ss, ds);
         };
         const long long wcs = (long long)SQ_HEAD_DIM * 2 * SQ_HEAD_DIM, wcd = (long long)SQ_HEAD_DIM * SQ_HEAD_DIM;
-        RUN(add(W(lay.head_w), D, b.whT, Gp, G, D, 1, 0, 0));
+        // (the head weight [G, D] -- 42 MB at G = 20 820 -- is NOT transposed: its dX product runs on the TN kernel from a
+        // gene-major copy of the 64 x G output gradient instead; the transpose was 60 of this launch's 85 us)
+        RUN(add(b.dout_lp, Gp, b.doutT, Bp, B, Gp, 1, 0, 0));
         for (int l = 0; l < c->depth; ++l) {
             const sq_vis_layer_offsets& L = lay.layer[l];
             RUN(add(W(L.ff2_w), D, b.wt[l].ff2, D, D, D, 1, 0, 0));
@@ -211,9 +214,9 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
     }
 
     // ---------------- head: out = LN(mean_n X) Wh^T + bh ----------------
-    RUN(sq_k_cast_pad(grad_out, G, b.dout_lp, dtype, Gp, B, G, st));
     { GemmArgs g = gemm_tn(b.dout_lp, Gp, w.xn, D, Gp_(lay.head_w), D, G, D, B); g.colsum_a = Gp_(lay.head_b); RUN(sq_launch_gemm_tn(g, dtype, st)); }
-    { GemmArgs g = gemm(b.dout_lp, Gp, b.whT, Gp, b.dxn, D, B, D, Gp); RUN(sq_launch_gemm(g, dtype, st)); }
+    // dxn[b, :] = sum_g dout[b, g] Wh[g, :]: both operands gene-major (doutT from the launch above, Wh as stored), K slices of G
+    { GemmArgs g = gemm_tn(b.doutT, Bp, W(lay.head_w), D, b.dxn, D, B, D, G); RUN(sq_launch_gemm_tn(g, dtype, st)); }
     RUN(sq_k_ln_rows_bwd(b.dxn, w.xm, Pf(lay.head_ln_g), nullptr, b.dxm, nullptr, Gp_(lay.head_ln_g), Gp_(lay.head_ln_b),
                          b.red_ws, B, D, st));
     RUN(bucket_done(0));
