@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsequoia_hip.so")
+LIB_PATH = os.environ.get("SQ_HIP_LIB") or os.path.join(_HERE, "libsequoia_hip.so")      # SQ_HIP_LIB: another build of the library (same-box A/B runs)
 
 SQ_F32 = 0
 SQ_BF16 = 1
