@@ -37,7 +37,7 @@ python tools/pmc_summary.py r04_pipeline_f16x3 gpurun_out/profiles_r04/r04_pipel
   "conv1_pool_f16x3=conv1_pool_x3_kernel<true>:131072"
 python tools/pmc_summary.py r04_vis_train_bf16 gpurun_out/profiles_r04/r04_vis_train_bf16_pmc.json $O/pmc_train_FETCH_SIZE $O/pmc_train_WRITE_SIZE $O/pmc_train_SQ_VALU_MFMA_BUSY_CYCLES \
   "gemm_bf16_M6400_N1024_K1024_b1=gemm_nt_kernel<unsigned short, 2, 2, false:102400" \
-  "gemmtn_bf16_M1024_N1024_K6400_b4=gemm_tn_kernel<unsigned short>:73728"
+  "gemmtn_bf16_M1024_N1024_K6400_b4=gemm_tn_ring_kernel:131072"
 python - <<'PY'
 import csv, glob, collections, re, json
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -66,6 +66,9 @@ cd /tmp; for w in "uni:--workload pipeline --embedder uni --slides 1 --steps 2 -
   f=$(ls $O/$t/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $R/gpurun_out/profiles_r04/r04_${t}_bf16_kernel_stats.csv
 done
 cd $R
+bash tools/r4_tnpmc.sh > /dev/null 2>&1; cp gpurun_out/r4_tn_sq_counters.txt gpurun_out/profiles_r04/r04_tn_sq_counters.txt
+python tools/tn_probe.py group 2>&1 | grep -v amdgpu.ids > gpurun_out/profiles_r04/r04_tn_probe_ring.txt
+python tools/nt_small.py 2>&1 | grep -v amdgpu.ids > gpurun_out/profiles_r04/r04_nt_small_cold_operands.txt
 SQ_BENCH_KERNELS=gpurun_out/profiles_r04/r04_vis_train_bf16_bench_kernels.json python bench.py --workload vis_train --no-secondary --no-cpu-baseline > gpurun_out/profiles_r04/r04_vis_train_bf16_bench_line.json 2>/dev/null
 ls -la gpurun_out/profiles_r04
 find $O -name "*.csv" -size +5M -delete
