@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmArgs p) {
 //     the other's MFMAs; the two accumulator sets are added through LDS in the epilogue, fixed order);
 //   * FOUR stages of 32 KiB (A rows + B rows, token-major as stored), three steps in flight, one counted
 //     `s_waitcnt vmcnt(8)` per step; steps beyond the slice's end are issued out of range (the buffer descriptor returns
-//     zeros), so the count is the same in every iteration; two raw `s_barrier`s per step with the two wave sets half a step
-//     apart (one issues its LDS-DMA requests while the other reads fragments and multiplies -- see "Schedule" in the kernel);
+//     zeros), so the count is the same in every iteration; ONE raw `s_barrier` per step, the two wave sets issue their LDS-DMA
+//     requests at opposite ends of the step, fragment reads run a step ahead of the MFMAs (see "Schedule" in the kernel);
 //   * tile walk: XCD x (blocks x, x + 8, ...) owns a contiguous run of the work list, and the list is ordered in 8 x 4
 //     patches of tiles -- the 32 blocks resident on an XCD read 8 A strips + 4 B strips (12 x 1.6 MB for K = 6400) instead
 //     of 4 x (4 + 2) = 24;
@@ -421,7 +421,8 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs p, con
     // requests in flight and puts `s_waitcnt vmcnt(0)` in front of it -- which would drain the ring every step.
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // Schedule.  Per step a CU stages 32 KiB through its vector-memory path (64 B/clk: 512 cycles -- and a wave that is issuing
-    // LDS-DMA requests issues nothing else meanwhile), reads 64 KiB of fragments (256 LDS cycles) and runs 512 cycles of MFMAs
+    // LDS-DMA requests issues nothing else meanwhile), reads 64 KiB of fragments (512 cycles at the 128 B/clk two waves per SIMD get
+    // out of `ds_read_b64_tr_b16`; no bank conflicts by the counters) and runs 512 cycles of MFMAs
     // per SIMD; a block-wide barrier costs ~165 cycles.  Measured with ablation switches (tools/tn_probe.py abl): when every wave
     // does request -> read -> multiply in order the three costs ADD (1560 cycles per step); with two barriers per step and the
     // wave sets half a step apart a phase is max(request + read, multiply) + barrier (1240 cycles).  What runs: ONE barrier per

@@ -170,6 +170,20 @@ def test_bad_arguments_fail_loudly():
     rc = _lib.lib().sq_linear(_lib.SQ_F32, _lib.ptr(A), 6, _lib.ptr(A), 6, None, None, 0, 0, 0, _lib.ptr(A), 0, 4, 4, 4, 6,
                               None, 0, _lib.stream_ptr())
     assert rc != 0 and b"multiple" in _lib.lib().sq_last_error()
+    # grouped weight gradient: five members, a null member, a misaligned member
+    X = torch.zeros(256, 128, device="cuda", dtype=torch.bfloat16)
+    dW = torch.zeros(128, 128, device="cuda")
+    arr = lambda ps: (ctypes.c_void_p * len(ps))(*ps)
+    lib = _lib.lib()
+    rc = lib.sq_linear_weight_grad_group(_lib.SQ_BF16, 5, arr([X.data_ptr()] * 5), arr([X.data_ptr()] * 5), arr([dW.data_ptr()] * 5), None,
+                                         128, 128, 128, 128, 128, 256, _lib.stream_ptr())
+    assert rc != 0 and b"members" in lib.sq_last_error()
+    rc = lib.sq_linear_weight_grad_group(_lib.SQ_BF16, 2, arr([X.data_ptr(), 0]), arr([X.data_ptr()] * 2), arr([dW.data_ptr()] * 2), None,
+                                         128, 128, 128, 128, 128, 256, _lib.stream_ptr())
+    assert rc != 0 and b"member 1" in lib.sq_last_error()
+    rc = lib.sq_linear_weight_grad_group(_lib.SQ_BF16, 2, arr([X.data_ptr(), X.data_ptr() + 2]), arr([X.data_ptr()] * 2), arr([dW.data_ptr()] * 2), None,
+                                         128, 128, 128, 128, 128, 256, _lib.stream_ptr())
+    assert rc != 0 and b"misaligned" in lib.sq_last_error()
 
 
 @pytest.mark.parametrize("M,N,K", [(256 * 9 + 37, 512, 320), (700, 256 + 64, 1024)])
