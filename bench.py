@@ -121,6 +121,11 @@ def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
         ach = dom["bytes"] / avg_s / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4)}
+    # both roofs, whichever side of the ridge the algorithmic intensity puts the label on (operands that live in L2 / the memory-side
+    # cache make a product just below the ridge look HBM-bound when it is not)
+    roof["both_roofs"] = {"tflops": round(dom["flops"] / avg_s / 1e12, 2), "mfma_frac": round(dom["flops"] / avg_s / 1e12 / PEAK[dtype_name], 4),
+                          "gbs": round(dom["bytes"] / avg_s / 1e9, 1), "hbm_frac": round(dom["bytes"] / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                          "flops_per_byte": round(flops_per_byte, 1), "ridge": round(ridge, 1)}
     roof.update({"traffic": None, "kernel": dom["name"], "avg_us": round(avg_s * 1e6, 2),
                  "launches_per_step": dom["count"] // max(steps, 1),
                  "share_of_instrumented_time": round(dom["total_ms"] / total_ms, 3),
