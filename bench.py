@@ -58,12 +58,70 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
+class PowerSampler:
+    """Package power and shader clock of this rank's GPU while the timed region runs (rank 0 only): `rocm-smi` from a second thread
+    every ~0.7 s.  The split-fp16 pipeline runs AT the 1400 W cap with the clock pulled to ~1.9 GHz: a rate quoted
+    against the 2.4 GHz peak says less than the same rate against the clock the chip actually sustains."""
+    MAX_SCLK_MHZ = 2400.0
+
+    def __init__(self, gpu_index):
+        import shutil
+        import threading
+        self.gpu = gpu_index
+        self.samples = []
+        self.stop = threading.Event()
+        self.th = threading.Thread(target=self._run, daemon=True) if shutil.which("rocm-smi") else None
+
+    def _read(self):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(self.gpu), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+        except Exception:
+            return None
+        p = re.search(r"Package Power \(W\): ([0-9.]+)", out)
+        c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+        return (float(p.group(1)), float(c.group(1))) if p and c else None
+
+    def _run(self):
+        while not self.stop.is_set():
+            v = self._read()
+            if v and not self.stop.is_set():
+                self.samples.append(v)
+            self.stop.wait(0.7)
+
+    def __enter__(self):
+        if self.th:
+            self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.th:
+            self.th.join(timeout=15)
+
+    def report(self):
+        s = self.samples[1:] if len(self.samples) > 2 else self.samples      # rocm-smi's power is a running average: drop the first reading
+        if not s:
+            return None
+        return {"package_w": round(sum(v[0] for v in s) / len(s), 1), "sclk_mhz": round(sum(v[1] for v in s) / len(s), 1),
+                "sclk_frac_of_max": round(sum(v[1] for v in s) / len(s) / self.MAX_SCLK_MHZ, 3), "samples": len(s),
+                "source": "rocm-smi --showpower --showclocks during the timed region (package power cap 1400 W)"}
+
+
+LAST_POWER = [None]
+
+
 def timed_region(step_fn, steps, warmup, world, device, flush_fn=None):
     for _ in range(warmup):
         step_fn()
     if flush_fn:
         flush_fn()
     barrier_sync(world)
+    rank = int(os.environ.get("RANK", "0"))
+    sampler = PowerSampler(device.index if hasattr(device, "index") and device.index is not None else 0) if rank == 0 and not os.environ.get("SQ_BENCH_NO_POWER") else None
+    if sampler:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
@@ -74,6 +132,9 @@ def timed_region(step_fn, steps, warmup, world, device, flush_fn=None):
         flush_fn()
     barrier_sync(world)
     dt = time.perf_counter() - t0
+    if sampler:
+        sampler.__exit__()
+        LAST_POWER[0] = sampler.report()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -664,9 +725,15 @@ def measure(name, args, rank, world, device, want_roofline=True, want_cpu=True):
     value = wl["slides_per_step"] * world * steps / dt
     out = {"value": round(value, 3), "unit": "slides/s", "steps": steps, "warmup": args.warmup,
            "ms_per_step": round(dt / steps * 1e3, 4), "timed_region_s": round(dt, 3), "dtype": args.dtype, "config": wl["config"]}
+    if LAST_POWER[0]:
+        out["power"] = LAST_POWER[0]
+        LAST_POWER[0] = None
     recs = []
     if want_roofline:
         roof, recs = roofline_from_profile(wl["step"], min(steps, 3), args.dtype, name)
+        if roof is not None and out.get("power") and roof.get("bound") == "mfma":
+            # the same fraction against the matrix peak AT THE CLOCK THE CHIP SUSTAINED in the timed region
+            roof["frac_at_sustained_clock"] = round(roof["frac"] / max(out["power"]["sclk_frac_of_max"], 1e-3), 4)
         if wl.get("flush"):
             wl["flush"]()
         if roof is not None and name == "pipeline":
@@ -770,7 +837,7 @@ def main():
             "warmup": res["warmup"], "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": res["config"],
             "roofline": res.get("roofline"), "cpu_baseline": res.get("cpu_baseline"), "timed_region_s": res["timed_region_s"],
-            "host_numa_binding": numa,
+            "host_numa_binding": numa, "power": res.get("power"),
             "ranks": torch.distributed.get_world_size() if world > 1 else 1,
             "backend": (torch.distributed.get_backend() if world > 1 else None)}
     if args.measure_traffic and rank == 0 and world == 1 and line.get("roofline"):
@@ -808,7 +875,7 @@ def main():
                 if r.returncode != 0 or not last:
                     raise RuntimeError((r.stderr or r.stdout)[-400:])
                 d = json.loads(last[-1])
-                sec[key] = {k: d[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "config", "roofline",
+                sec[key] = {k: d.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "config", "roofline", "power",
                                               "accuracy_vs_reference") if k in d}
             except Exception as e:                      # a secondary failure must not cost the headline line
                 sec[key] = {"error": f"{type(e).__name__}: {e}"}
