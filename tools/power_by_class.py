@@ -62,8 +62,46 @@ def run(name, M, N, K, conv=None, res=True, seconds=7.0):
     print(f"{name:34s} {us:8.1f} us  {pw:7.0f} W  sclk {ck:5.0f} MHz  {pw * us * 1e-6:7.3f} J per launch   {3 * 2.0 * M * N * K / us / 1e6:7.0f} TF of fp16 MFMA work", flush=True)
 
 
+def run_torch(name, fn, work, unit, seconds=6.0):
+    """the same sampling around a torch op (context figures: a plain HBM copy, the vendor library's fp16 / bf16 GEMM)"""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record(); torch.cuda.synchronize()
+    n_iter = max(10, int(seconds * 1e3 / a.elapsed_time(b)))
+    samples, stop = [], threading.Event()
+    def sampler():
+        t0 = time.time()
+        while not stop.is_set():
+            v = smi()
+            if time.time() - t0 > seconds * 0.45:
+                samples.append(v)
+    th = threading.Thread(target=sampler); th.start()
+    a.record()
+    for _ in range(n_iter):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    stop.set(); th.join()
+    samples = samples[:-1] or samples
+    us = a.elapsed_time(b) / n_iter * 1e3
+    pw = sum(s[0] for s in samples) / len(samples); ck = sum(s[1] for s in samples) / len(samples)
+    time.sleep(2.0)
+    print(f"{name:34s} {us:8.1f} us  {pw:7.0f} W  sclk {ck:5.0f} MHz  {pw * us * 1e-6:7.3f} J per call     {work / us / 1e6:7.2f} {unit}", flush=True)
+
+
 if __name__ == "__main__":
     print("idle:", smi())
+    if len(sys.argv) > 1 and sys.argv[1] == "context":
+        x = torch.randn(1 << 30, device="cuda"); y = torch.empty_like(x)                     # 4 GiB each
+        run_torch("HBM copy 4 GiB -> 4 GiB (torch)", lambda: y.copy_(x), 2.0 * x.numel() * 4, "TB/s (read + write)")
+        del x, y
+        for dt, nm in ((torch.float16, "fp16"), (torch.bfloat16, "bf16")):
+            A = torch.randn(8192, 8192, device="cuda").to(dt); B = torch.randn(8192, 8192, device="cuda").to(dt)
+            run_torch(f"hipBLASLt {nm} 8192^3 (torch.matmul)", lambda: torch.matmul(A, B.T), 2.0 * 8192 ** 3, "PFLOP/s x 1e-3" if False else "TFLOP/s")
+            Az = torch.zeros_like(A)
+            run_torch(f"  the same, A all zeros", lambda: torch.matmul(Az, B.T), 2.0 * 8192 ** 3, "TFLOP/s")
+        sys.exit(0)
     run("3x3 14x14 (M196000 N256 K2304)", 196000, 256, 2304, conv=(1000, 14, 256), res=False)
     run("3x3 28x28 (M784000 N128 K1152)", 784000, 128, 1152, conv=(1000, 28, 128), res=False)
     run("reduce 14x14 (M196000 N256 K1024)", 196000, 256, 1024, res=False)
