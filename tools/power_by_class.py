@@ -16,7 +16,7 @@ def smi():
     return (float(p.group(1)) if p else float("nan"), int(c.group(1)) if c else 0)
 
 
-def run(name, M, N, K, conv=None, res=True, seconds=7.0):
+def run(name, M, N, K, conv=None, res=True, seconds=7.0, zeros=False):
     g = torch.Generator(device="cuda").manual_seed(1)
     if conv:
         n, H, Cin = conv
@@ -30,6 +30,9 @@ def run(name, M, N, K, conv=None, res=True, seconds=7.0):
     W = torch.randn(2, N, K, device="cuda", generator=g).half()
     C = torch.empty(2, M, N, device="cuda", dtype=torch.float16)
     R = torch.randn(2, M, N, device="cuda", generator=g).half() if res else None
+    if zeros:                                # the same launch on all-zero activations and weights: what is left is not multiplier switching
+        A.zero_(); W.zero_()
+        if res: R.zero_()
     bias = torch.randn(N, device="cuda")
     fn = lambda: _lib.check(lib.sq_linear_x3(1, _lib.ptr(A[0]), _lib.ptr(A[1]), lda, _lib.ptr(W[0]), _lib.ptr(W[1]), K, _lib.ptr(bias), None,
                                              _lib.ptr(R[0]) if res else None, _lib.ptr(R[1]) if res else None, N, 2,
@@ -108,3 +111,6 @@ if __name__ == "__main__":
     run("reduce 28x28 (M784000 N128 K512)", 784000, 128, 512, res=False)
     run("expand 14x14 (M196000 N1024 K256)", 196000, 1024, 256, res=True)
     run("expand 28x28 (M784000 N512 K128)", 784000, 512, 128, res=True)
+    run("3x3 14x14, all operands zero", 196000, 256, 2304, conv=(1000, 14, 256), res=False, zeros=True)
+    run("reduce 14x14, all operands zero", 196000, 256, 1024, res=False, zeros=True)
+    run("expand 28x28, all operands zero", 784000, 512, 128, res=True, zeros=True)
