@@ -29,6 +29,9 @@ def bind_to_gpu_numa_node(device_index):
     threads with it (see below).  Never fails: returns a dict that
     says what was done (bench.py prints it), or why nothing was."""
     info = {"gpu": int(device_index), "node": None, "cpus": None, "bound": False}
+    if os.environ.get("SQ_NO_NUMA_BIND", "0") not in ("", "0"):
+        info["why"] = "SQ_NO_NUMA_BIND is set"
+        return info
     try:
         import torch
         prop = torch.cuda.get_device_properties(device_index)
@@ -72,7 +75,11 @@ def init_distributed():
     if torch.cuda.is_available():
         torch.cuda.set_device(device)
         if world > 1:
-            bind_to_gpu_numa_node(local)
+            # narrows this thread's CPU mask (threads / DataLoader workers started later inherit it) and caps torch's intra-op
+            # pool at 16 threads; SQ_NO_NUMA_BIND=1 opts out
+            info = bind_to_gpu_numa_node(local)
+            if rank == 0:
+                print(f"[sequoia-pub_amd] host NUMA binding: {info}", flush=True)
     if world > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl" if torch.cuda.is_available() else "gloo")

@@ -456,6 +456,7 @@ int g_p8_on = -1;                  // sq_dbg_set key 14 (tests): 0 / 1 overrides
 int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
     if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.rowbias || !a.vec_epi) return 0;
     if (a.ln64_g && (a.N % 64 || !a.ln64_b)) return 0;
+    if (a.ln64_g && a.gelu_grad_of) return 0;          // no epilogue of this kernel does both (LayerNorm(64) is forward, GELU' backward)
     static int on = -1, min_tiles = 0, min_k = 0, on128 = 0;
     if (on < 0) {
         const char* e = getenv("SQ_GEMM_P8");
@@ -522,6 +523,8 @@ int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     SQ_REQUIRE(!a.ln64_g || (a.ln64_b && a.N % 64 == 0 && a.vec_epi), "gemm_p8: the LayerNorm(64) epilogue needs N %% 64 == 0 and 16-byte aligned epilogue operands");
     SQ_REQUIRE(!a.rowbias, "gemm_p8: no row-bias epilogue");
+    SQ_REQUIRE(!(a.ln64_g && a.gelu_grad_of), "gemm_p8: LayerNorm(64) and GELU' epilogues cannot be combined");
+    SQ_REQUIRE(a.K % 8 == 0, "gemm_p8: K=%d must be a multiple of 8 (16-byte operand chunks), also when the tile is forced", a.K);
     static int env_gm = -1, env_persist = -1, env_skew = -2;
     if (env_gm < 0) { const char* e = getenv("SQ_GEMM_P8_GROUP_M"); env_gm = e ? atoi(e) : 8; }
     if (env_persist < 0) { const char* e = getenv("SQ_GEMM_P8_PERSIST"); env_persist = e ? atoi(e) : 1; }

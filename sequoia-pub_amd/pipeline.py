@@ -63,17 +63,19 @@ class SlidePipeline:
         side.wait_event(ev)
         f.record_stream(side)
         with torch.cuda.stream(side):
-            cf, lab = self.cluster(f.unsqueeze(0))
             if host_flag is not None:
-                ev.synchronize()                   # long complete: the k-Means above polled the host behind it
+                # read the flag BEFORE clustering: k-Means never sees non-finite features.  The host would block on this
+                # slide's embedding inside k-Means' first convergence poll anyway, and the main stream already holds the
+                # next slide's embedding, so the chip is not idle while it waits here
+                ev.synchronize()
                 if int(host_flag[0]) != 0:         # an fp16 plane overflowed in this slide: embed it again in exact fp32
                     import warnings
                     warnings.warn("split-fp16 embedder: an activation left fp16's range in one slide; the slide is re-embedded in exact fp32",
                                   RuntimeWarning, stacklevel=2)
                     self.nonfinite_reruns = getattr(self, "nonfinite_reruns", 0) + 1
                     f = self.resnet.exact_twin().extract_patches_u8(p.to(f.device), 128)
-                    cf, lab = self.cluster(f.unsqueeze(0))
                     f.record_stream(main)
+            cf, lab = self.cluster(f.unsqueeze(0))
             fin = torch.cuda.Event()
             fin.record(side)
         cf.record_stream(main)

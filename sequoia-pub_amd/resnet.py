@@ -152,15 +152,20 @@ class ResNet50(nn.Module):
 
     # ---- the reduced range of the split-fp16 mode ----------------------------------------------------------------
     def exact_twin(self):
-        """The same network in the exact fp32 mode (shares the parameters): what a launch group is re-run in when the
-        split-fp16 mode overflowed (an activation >= 65504; sq_resnet50_extract_checked)."""
+        """The same network in the exact fp32 mode (a copy of the parameters, refreshed only when they changed): what a
+        launch group is re-run in when the split-fp16 mode overflowed (an activation >= 65504; sq_resnet50_extract_checked)."""
+        key = (self.conv1.weight.device, tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()))
         tw = self.__dict__.get("_twin")
         if tw is None:
-            tw = ResNet50(compute_dtype="fp32")
+            tw = ResNet50(num_classes=self.fc.out_features, compute_dtype="fp32")
             tw._built = True
             self.__dict__["_twin"] = tw                  # not a registered submodule: state_dict() keeps the reference's keys
-        tw.load_state_dict(self.state_dict())
-        return tw.to(self.conv1.weight.device).eval()
+            self.__dict__["_twin_key"] = None
+        if self.__dict__.get("_twin_key") != key:        # (load_state_dict bumps every version: synced once per change, so the twin's pack cache hits)
+            tw.load_state_dict(self.state_dict(), strict=False)
+            tw.to(self.conv1.weight.device).eval()
+            self.__dict__["_twin_key"] = key
+        return tw
 
     def new_flag(self):
         """A zeroed device word for sq_resnet50_extract_checked's non-finite flag."""
@@ -210,10 +215,13 @@ class ResNet50(nn.Module):
         x = x.to(dev, torch.float32).contiguous()
         flag = self.new_flag() if self.compute_dtype == _lib.SQ_F16X3 else None
         feats = self._run(x_f32=x, flag=flag)
-        return self._resolve_nonfinite(feats, flag, on_nonfinite,
-                                       lambda: torch.cat([self.exact_twin()._run(x_f32=x[i:i + 128]) for i in range(0, x.shape[0], 128)]))
 
-    @torch.no_grad()
+        def rerun():
+            tw = self.exact_twin()                      # built and synced once, not per chunk
+            step = max(1, min(128, tw.max_sub_batch(x.shape[2])))
+            return torch.cat([tw._run(x_f32=x[i:i + step]) for i in range(0, x.shape[0], step)])
+        return self._resolve_nonfinite(feats, flag, on_nonfinite, rerun)
+
     def max_sub_batch(self, S):
         """Largest launch group the 2 GiB buffer-descriptor limit allows at patch size S (sq_resnet50_extract's check): the
         [n, S/2, S/2, 64] activation planes, and in fp32 mode the [n (S/2)^2, 152] im2col matrix of the stem."""
@@ -221,6 +229,7 @@ class ResNet50(nn.Module):
         per = (S // 2) ** 2 * (152 if self.compute_dtype == _lib.SQ_F32 else 64) * es
         return max(1, ((1 << 31) - 1) // per)
 
+    @torch.no_grad()
     def extract_patches_u8(self, patches, sub_batch=500, on_nonfinite="rerun", flag=None):
         """uint8 HWC patches [n, S, S, 3] -> f32 [n, 2048]; fuses compute_features_hdf5.py:119-120's transform.
         Patches go through in launch groups of <= sub_batch (clamped to what the 2 GiB buffer-descriptor limit allows for

@@ -151,5 +151,16 @@ def test_numa_binding_helper_never_fails():
     entry (this container); on an 8-GPU node it pins each rank's host threads next to its GPU."""
     from sequoia_pub_amd.cli.common import _parse_cpulist, bind_to_gpu_numa_node
     assert _parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and _parse_cpulist("") == set()
-    info = bind_to_gpu_numa_node(0)
-    assert info["gpu"] == 0 and isinstance(info["bound"], bool) and (info["bound"] or "why" in info)
+    import os
+    import torch
+    aff, nthr = os.sched_getaffinity(0), torch.get_num_threads()
+    try:
+        info = bind_to_gpu_numa_node(0)
+        assert info["gpu"] == 0 and isinstance(info["bound"], bool) and (info["bound"] or "why" in info)
+        os.environ["SQ_NO_NUMA_BIND"] = "1"
+        off = bind_to_gpu_numa_node(0)
+        assert off["bound"] is False and "SQ_NO_NUMA_BIND" in off["why"]
+    finally:                                    # the helper changes process-wide state: leave the test process as it was
+        os.environ.pop("SQ_NO_NUMA_BIND", None)
+        os.sched_setaffinity(0, aff)
+        torch.set_num_threads(nthr)
