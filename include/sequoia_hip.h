@@ -253,6 +253,11 @@ int sq_resnet50_extract_checked(int dtype, const void* weights, const float* bia
 
 /* dst_bf16[i] = bf16(src[i]) -- refresh of the bf16 parameter shadow after an optimizer step */
 int sq_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, sq_stream_t stream);
+/* dst[i] = fp32(src_bf16[i]) -- with the call above the pack / unpack of the bf16 gradient exchange (BASELINE config 4: "RCCL grad
+ * all-reduce over xGMI, bf16"; the reference trains on one device, src/main.py:78, so there is no counterpart to cite): a gradient
+ * bucket is cast to bf16, summed over the ranks in bf16 (half the ring traffic of the fp32 form), cast back into the fp32 flat
+ * gradient that AdamW reads (train.py FusedTrainStep) */
+int sq_cast_bf16_to_f32(const void* src_bf16, float* dst, size_t n, sq_stream_t stream);
 
 /* ------------------------------------------------------------------------------
  * Fused linear layer  C = act(A . W^T + bias + residual)   -- the nn.Linear call sites of

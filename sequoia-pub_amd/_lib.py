@@ -157,6 +157,8 @@ def _declare(lib):
     lib.sq_linear_x3.argtypes = [i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.sq_cast_f32_to_bf16.restype = i32
     lib.sq_cast_f32_to_bf16.argtypes = [vp, vp, sz, vp]
+    lib.sq_cast_bf16_to_f32.restype = i32
+    lib.sq_cast_bf16_to_f32.argtypes = [vp, vp, sz, vp]
     for name, (res, args) in _OPTIONAL.items():
         if hasattr(lib, name):
             fn = getattr(lib, name)

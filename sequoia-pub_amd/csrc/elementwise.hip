@@ -272,6 +272,14 @@ __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __rest
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i] = bf16_to_f32(src[i]);
 }
+// 8 elements per thread: one 16-byte load, two 16-byte stores (both pointers 16-byte aligned; the launcher checks)
+__global__ __launch_bounds__(256) void bf16_to_f32_x8_kernel(const u32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 v = src[i];
+        dst[2 * i] = f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+        dst[2 * i + 1] = f32x4{__uint_as_float(v[2] << 16), __uint_as_float(v[2] & 0xffff0000u), __uint_as_float(v[3] << 16), __uint_as_float(v[3] & 0xffff0000u)};
+    }
+}
 
 // 64x64 tile through LDS (+1 padding), coalesced on both sides; zero-fills dst columns [R, ldd)
 template <typename E>
@@ -427,8 +435,17 @@ int sq_k_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
 }
 
 int sq_k_bf16_to_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n);
-    SQ_LAUNCH_CHECK();
+    size_t done = 0;
+    if (n >= 8 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+        const size_t n8 = n / 8;
+        hipLaunchKernelGGL(bf16_to_f32_x8_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, s, (const u32x4*)src, (f32x4*)dst, n8);
+        SQ_LAUNCH_CHECK();
+        done = n8 * 8;
+    }
+    if (done < n) {
+        hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n - done, 256)), dim3(256), 0, s, src + done, dst + done, n - done);
+        SQ_LAUNCH_CHECK();
+    }
     return SQ_OK;
 }
 

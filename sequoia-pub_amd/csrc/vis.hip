@@ -269,6 +269,11 @@ extern "C" int sq_cast_f32_to_bf16(const float* src, void* dst, size_t n, sq_str
     return sq_k_f32_to_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream);
 }
 
+extern "C" int sq_cast_bf16_to_f32(const void* src, float* dst, size_t n, sq_stream_t stream) {
+    SQ_REQUIRE(src && dst, "cast: null pointer");
+    return sq_k_bf16_to_f32((const bf16_t*)src, dst, n, (hipStream_t)stream);
+}
+
 extern "C" int sq_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
                          int ldres, int res_dtype, int act, void* C, int out_dtype, int ldc, int M, int N, int K, void* workspace,
                          size_t workspace_bytes, sq_stream_t stream) {

@@ -125,7 +125,13 @@ class FusedTrainStep:
     single-device update on the concatenated batch.
     """
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=1, metrics=False):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=1, metrics=False,
+                 grad_exchange=None):
+        """grad_exchange: 'bf16' | 'fp32' -- the wire format of the gradient all-reduce (world_size > 1).  Default: the
+        environment's SQ_DDP_GRAD_EXCHANGE, else 'bf16' for a model in the bf16 compute mode (BASELINE config 4: "RCCL grad
+        all-reduce over xGMI, bf16": half the ring traffic) and 'fp32' for the exact fp32 mode.  bf16: every bucket is cast to
+        bf16 behind its completion event, summed over the ranks in bf16, cast back into the fp32 flat gradient AdamW reads;
+        master weights, moments and the local accumulation stay fp32."""
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.world = world_size
@@ -137,11 +143,22 @@ class FusedTrainStep:
         # a side stream as soon as the backward pass has recorded its event.  SQ_FORCE_BUCKETS=1 exercises the
         # same path on a single rank.
         self.overlap = world_size > 1 or os.environ.get("SQ_FORCE_BUCKETS") == "1"
+        if grad_exchange is None:
+            grad_exchange = os.environ.get("SQ_DDP_GRAD_EXCHANGE") or ("bf16" if model.compute_dtype == _lib.SQ_BF16 else "fp32")
+        if grad_exchange not in ("bf16", "fp32"):
+            raise ValueError(f"grad_exchange {grad_exchange!r}: 'bf16' or 'fp32'")
+        self.grad_exchange = grad_exchange
+        self.exchange_bytes_per_step = 0              # payload handed to all_reduce per step (all buckets), set below
+        self._wire = None
         if self.overlap:
             dev = model.flat.device
             self.buckets = grad_buckets(model)
             self.comm_stream = torch.cuda.Stream(device=dev)
             self.events = [torch.cuda.Event() for _ in self.buckets]
+            n_el = sum(hi - lo for lo, hi in self.buckets)
+            self.exchange_bytes_per_step = n_el * (2 if grad_exchange == "bf16" else 4)
+            if grad_exchange == "bf16":
+                self._wire = torch.empty(model.flat.numel(), dtype=torch.bfloat16, device=dev)     # bucket i travels as _wire[lo:hi]
             with torch.cuda.device(dev):
                 for e in self.events:
                     e.record()              # instantiates the hipEvent_t the C side records into
@@ -192,9 +209,16 @@ class FusedTrainStep:
                 self.comm_stream.wait_event(ev)
                 if not empty and sample and i == 0:
                     tc0.record(self.comm_stream)
-                if reduce_:
+                if reduce_ or self._wire is not None:
                     with torch.cuda.stream(self.comm_stream):
-                        dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
+                        if self._wire is None:
+                            dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
+                        else:                 # bf16 on the wire: pack -> sum over ranks in bf16 -> unpack into the fp32 gradient
+                            cs = _lib.stream_ptr(dev)                   # inside the block: the communication stream
+                            _lib.check(_lib.lib().sq_cast_f32_to_bf16(_lib.ptr(gflat[lo:hi]), _lib.ptr(self._wire[lo:hi]), hi - lo, cs))
+                            if reduce_:
+                                dist.all_reduce(self._wire[lo:hi], op=dist.ReduceOp.SUM)
+                            _lib.check(_lib.lib().sq_cast_bf16_to_f32(_lib.ptr(self._wire[lo:hi]), _lib.ptr(gflat[lo:hi]), hi - lo, cs))
             if not empty and sample:
                 tc1.record(self.comm_stream)
                 self._tm["pending"] = (tb0, tb1, tc0, tc1)
@@ -234,6 +258,8 @@ class FusedTrainStep:
             return None
         out = {k: round(self._tm[k] / n, 4) for k in ("backward_ms", "allreduce_span_ms", "exposed_ms")}
         out["sampled_steps"] = n
+        out["wire_format"] = self.grad_exchange
+        out["bytes_exchanged_per_step"] = self.exchange_bytes_per_step
         if reset:
             self._tm.update(n=0, backward_ms=0.0, allreduce_span_ms=0.0, exposed_ms=0.0)
         return out

@@ -31,9 +31,11 @@ def main():
     y = (torch.rand(6, 50, generator=g) * 8).cuda()
     rows = slice(0, 4) if rank == 0 else slice(4, 6)            # ragged: 4 + 2 slides
 
+    wire = sys.argv[2] if len(sys.argv) > 2 else "fp32"         # wire format of the gradient exchange: fp32 | bf16
     m = model()
-    step = sq_train.FusedTrainStep(m, lr=1e-3, world_size=world)
+    step = sq_train.FusedTrainStep(m, lr=1e-3, world_size=world, grad_exchange=wire)
     assert len(step.buckets) == CFG["depth"] + 1
+    assert step.exchange_bytes_per_step == m.flat.numel() * (2 if wire == "bf16" else 4)
     out = step.step(x[rows], y[rows], n_global=6 * 50)          # step 1: both ranks hold slides
     assert out is not None
     g1 = m._gflat.clone()
@@ -47,6 +49,11 @@ def main():
     flat = m.flat.detach().clone()
     tr = step.timing_report()                                   # step 1 was sampled: backward time, all-reduce span, exposed part
     assert tr is not None and tr["sampled_steps"] == 1 and tr["backward_ms"] > 0 and tr["allreduce_span_ms"] > 0 and tr["exposed_ms"] >= 0, tr
+    assert tr["wire_format"] == wire and tr["bytes_exchanged_per_step"] == step.exchange_bytes_per_step, tr
+    # the exchanged gradient itself must be bit-identical on both ranks (bf16 wire: both unpack the same summed bf16 values)
+    gb = [torch.empty_like(g2) for _ in range(world)]
+    dist.all_gather(gb, g2)
+    assert torch.equal(gb[0], gb[1]), "ranks hold different gradients after the exchange"
 
     # every rank must hold the same parameters afterwards
     both = [torch.empty_like(flat) for _ in range(world)]
@@ -66,9 +73,20 @@ def main():
             return float((a - b).abs().max() / b.abs().max())
         e1, e2 = rel(g1, r1), rel(g2, r2)
         dp = (flat - ref.flat.detach()).abs()
-        print(f"ddp2: grad rel err step1 {e1:.2e} step2 {e2:.2e}; param max diff {float(dp.max()):.2e} mean {float(dp.mean()):.2e}")
-        assert e1 < 1e-5 and e2 < 1e-5
-        assert float(dp.max()) < 2.5e-3 and float(dp.mean()) < 1e-6      # lr = 1e-3: a sign flip of a ~zero gradient moves 2 lr at most
+        # per tensor (every state_dict entry is a slice of the flat buffer)
+        worst = 0.0
+        for name, t in ref.state_dict().items():
+            off = (t.data_ptr() - ref.flat.data_ptr()) // 4
+            if 0 <= off < ref.flat.numel() and t.numel() and float(r1[off:off + t.numel()].abs().max()) > 0:
+                worst = max(worst, rel(g1[off:off + t.numel()], r1[off:off + t.numel()]))
+        print(f"ddp2 [{wire} wire, {step.exchange_bytes_per_step} B/step]: grad rel err step1 {e1:.2e} step2 {e2:.2e}, worst tensor {worst:.2e}; "
+              f"param max diff {float(dp.max()):.2e} mean {float(dp.mean()):.2e}")
+        if wire == "fp32":
+            assert e1 < 1e-5 and e2 < 1e-5 and worst < 1e-4
+            assert float(dp.max()) < 2.5e-3 and float(dp.mean()) < 1e-6      # lr = 1e-3: a sign flip of a ~zero gradient moves 2 lr at most
+        else:               # two bf16 roundings (pack, sum): 2^-8 of a value at worst, relative to the tensor's maximum
+            assert e1 < 1e-2 and e2 < 1e-2 and worst < 1e-2
+            assert float(dp.max()) < 2.5e-3 and float(dp.mean()) < 2e-5
         open(sys.argv[1], "w").write("ok")
     dist.barrier()
     dist.destroy_process_group()

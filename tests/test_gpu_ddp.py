@@ -13,12 +13,15 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_two_rank_fused_step_equals_one_rank_step(tmp_path):
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_two_rank_fused_step_equals_one_rank_step(tmp_path, wire):
+    """Both wire formats of the gradient exchange: fp32 (exact: == the one-rank step to 1e-5) and bf16 (BASELINE config 4's
+    "bf16" all-reduce, half the bytes: within 1e-2 per tensor, both ranks bit-identical)."""
     ok = tmp_path / "ok"
     port = 29500 + os.getpid() % 2000
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(HERE, "ddp_worker.py"), str(ok)]
+           "--master-port", str(port), os.path.join(HERE, "ddp_worker.py"), str(ok), wire]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0
@@ -64,6 +67,8 @@ def test_config4_train_kfold_two_ranks_equal_one_rank_at_the_same_global_batch(t
     assert two["check"]["ranks_hold_identical_parameters"] is True
     ex = two["check"]["gradient_exchange_ms_per_step"]           # what a first multi-GPU run needs to explain its scaling
     assert ex is not None and ex["backward_ms"] > 0 and ex["allreduce_span_ms"] > 0 and one["check"]["gradient_exchange_ms_per_step"] is None
+    # config 4 says bf16: a bf16 model exchanges bf16 buckets -- 2 bytes per parameter per step (107.5 MB at this size), not 4
+    assert ex["wire_format"] == "bf16" and 100e6 < ex["bytes_exchanged_per_step"] < 115e6, ex
     assert two["config"]["slides"] == 32 and one["config"]["slides"] == 32
     a, b = torch.load(p2), torch.load(p1)
     d = (a - b).abs()
