@@ -36,6 +36,10 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
                            const uint16_t* t1, long long plT1, const uint16_t* w2, size_t w2_bytes, const float* b2, const float* cs2, int W, int HW,
                            long long P, uint16_t* frag, int w_tiled, hipStream_t stream);
 size_t sq_chain_x3_frag_bytes();
+bool sq_chain_x3w_eligible(int c, int n2);
+int sq_launch_chain_x3w(int f16, int c, const uint16_t* t2, long long plT2, const uint16_t* res, long long plRes, uint16_t* y, long long plY,
+                        uint16_t* t1n, long long plT1n, int n2, const uint16_t* w3, const uint16_t* w1n, long long plW, size_t w3_bytes, size_t w1n_bytes,
+                        const float* b3, const float* cs3, const float* b1n, const float* cs1n, long long P, int w_tiled, hipStream_t stream);
 int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, const uint16_t* w152_hi, long long w_plane, const float* bias,
                             const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream);
 
@@ -408,6 +412,23 @@ extern "C" int sq_resnet50_extract_checked(int dtype, const void* weights, const
                 ci = cnext;
                 xi = free_[2];
                 t1i = x3_tail ? free_[0] : t1_idx;
+                H = OH;
+                continue;
+            }
+            // split modes, plain bottlenecks of the 128- and 256-plane stages (28 x 28, 14 x 14): expand 1x1 + identity + ReLU and the
+            // NEXT block's reduce 1x1 in one launch (chain_x3w.hip; SQ_RESNET_NO_CHAINW=1: two launches): y is written once and not
+            // read back; t1' lands in the buffer conv1's output occupied (dead once conv2 has read it)
+            if (x3 && !has_ds && !sq_env_flag("SQ_RESNET_NO_CHAINW") && c3.k == 1 && c3.cout == 4 * c3.cin && cnext < SQ_RESNET50_CONVS &&
+                lay.conv[cnext].k == 1 && lay.conv[cnext].stride == 1 && lay.conv[cnext].cin == c3.cout &&
+                sq_chain_x3w_eligible(c3.cin, lay.conv[cnext].cout)) {
+                const sq_conv_desc& n1 = lay.conv[cnext];
+                auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
+                RUN(sq_launch_chain_x3w(f16, c3.cin, (const uint16_t*)t2, act_plane, (const uint16_t*)x, act_plane, (uint16_t*)y, act_plane,
+                                        (uint16_t*)t1, act_plane, n1.cout, (const uint16_t*)W(c3), (const uint16_t*)W(n1), lay.w_total, rest(c3), rest(n1),
+                                        bias + c3.b_off, colscale + c3.b_off, bias + n1.b_off, colscale + n1.b_off, (long long)n * OH * OH, 1, st));
+                ci = cnext;
+                xi = free_[2];
+                t1i = t1_idx;
                 H = OH;
                 continue;
             }

@@ -171,6 +171,60 @@ def test_conv_x3_halo_staged_3x3(Cin, Cout, H, n, halo, fmt):
     assert rel_err(planes_out, out) < TOL[fmt][1], rel_err(planes_out, out)
 
 
+def _linear_x3_planes(fmt, A, W, cs, bias, res, M, N, K):
+    """sq_linear_x3 on plane tensors [2, ., .] already on the device; returns the output planes [2, M, N]."""
+    out = torch.full((2, M, N), float("nan"), device="cuda", dtype=PLANE[fmt])
+    _lib.check(_lib.lib().sq_linear_x3(fmt, _lib.ptr(A[0]), _lib.ptr(A[1]), K, _lib.ptr(W[0]), _lib.ptr(W[1]), K, _lib.ptr(bias), _lib.ptr(cs),
+                                       _lib.ptr(res[0]) if res is not None else None, _lib.ptr(res[1]) if res is not None else None, N, 2,
+                                       _lib.ptr(out[0]), _lib.ptr(out[1]), None, N, M, N, K, None, _lib.stream_ptr()))
+    return out
+
+
+@pytest.mark.parametrize("fmt", [1, 0])
+@pytest.mark.parametrize("C,P", [(256, 128), (256, 1000), (256, 3 * 196 + 5), (128, 256), (128, 1000), (128, 2 * 784 + 77)])
+def test_chain_x3w_is_bit_identical_to_the_two_launches(C, P, fmt):
+    """chain_x3w.hip (28 x 28 / 14 x 14 stages: expand 1x1 + identity + ReLU + the next block's reduce 1x1 in one launch, products
+    transposed so that y stays in the wave that made it) against the two gemm_x3.hip launches it replaces, on the same planes:
+    y and t1' must be equal bit for bit -- ragged last tiles, per-channel power-of-two weight scales, both plane formats."""
+    _lib.require_gpu()
+    lib = _lib.lib()
+    vp = ctypes.c_void_p
+    lib.sq_dbg_chain_x3w.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong] + [vp] * 16 + [ctypes.c_int, vp]
+    g = torch.Generator().manual_seed(C * 13 + P + fmt)
+    N1 = 4 * C
+    t2 = torch.relu(torch.randn(P, C, generator=g)) * torch.rand(P, 1, generator=g) * 2
+    res = torch.relu(torch.randn(P, N1, generator=g)) * 1.5
+    w3 = torch.randn(N1, C, generator=g) * (1.0 / np.sqrt(C)) + torch.arange(N1)[:, None] * 1e-4
+    w1 = torch.randn(C, N1, generator=g) * (1.0 / np.sqrt(N1)) + torch.arange(C)[:, None] * 1e-4
+    s3 = 2.0 ** (torch.arange(N1) % 5 + 7).float() if fmt else torch.ones(N1)
+    s1 = 2.0 ** (torch.arange(C) % 3 + 9).float() if fmt else torch.ones(C)
+    b3, b1 = torch.randn(N1, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    cs3, cs1 = (1.0 / s3).cuda(), (1.0 / s1).cuda()
+    T2, R = torch.stack(split(t2, fmt)).cuda(), torch.stack(split(res, fmt)).cuda()
+    # both weights in ONE allocation per plane (the fused launch takes one plane distance for both)
+    wall = torch.cat([(w3 * s3[:, None]).reshape(-1), (w1 * s1[:, None]).reshape(-1)])
+    Wp = torch.stack(split(wall, fmt)).cuda().contiguous()
+    W3 = Wp[:, :N1 * C].view(2, N1, C)
+    W1 = Wp[:, N1 * C:].view(2, C, N1)
+    assert W3[1].data_ptr() - W3[0].data_ptr() == W1[1].data_ptr() - W1[0].data_ptr()
+    W3c, W1c = W3.contiguous(), W1.contiguous()                 # (sq_linear_x3 wants each weight's planes in their own allocation)
+    y_ref = _linear_x3_planes(fmt, T2, W3c, cs3, b3, R, P, N1, C)
+    t1_ref = _linear_x3_planes(fmt, y_ref, W1c, cs1, b1, None, P, C, N1)
+    y = torch.full((2, P, N1), float("nan"), device="cuda", dtype=PLANE[fmt])
+    t1 = torch.full((2, P, C), float("nan"), device="cuda", dtype=PLANE[fmt])
+    rc = lib.sq_dbg_chain_x3w(fmt, C, P, _lib.ptr(T2[0]), _lib.ptr(T2[1]), _lib.ptr(R[0]), _lib.ptr(R[1]), _lib.ptr(y[0]), _lib.ptr(y[1]),
+                              _lib.ptr(t1[0]), _lib.ptr(t1[1]), _lib.ptr(W3[0]), _lib.ptr(W3[1]), _lib.ptr(W1[0]), _lib.ptr(W1[1]),
+                              _lib.ptr(b3), _lib.ptr(cs3), _lib.ptr(b1), _lib.ptr(cs1), 0, _lib.stream_ptr())
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    yi, yr = y.view(torch.int16), y_ref.view(torch.int16)
+    ti, tr = t1.view(torch.int16), t1_ref.view(torch.int16)
+    assert torch.isfinite(y_ref.float()).all() and float(y_ref[0].float().abs().max()) > 0.5
+    bad_y, bad_t = int((yi != yr).sum()), int((ti != tr).sum())
+    assert bad_y == 0, (bad_y, yi.numel(), rel_err(y[0].float().cpu(), y_ref[0].float().cpu()))
+    assert bad_t == 0, (bad_t, ti.numel(), rel_err(t1[0].float().cpu(), t1_ref[0].float().cpu()))
+
+
 def _model(mode):
     sd = ro.init_resnet50_state_dict(seed=99, perturb_bn=True)
     m = resnet50(pretrained=False, compute_dtype=mode)
@@ -223,15 +277,15 @@ def test_resnet50_x3_fused_chain_is_bit_identical(monkeypatch, mode):
     p = torch.from_numpy(synth.patches_u8(5, n_patches=3, size=224)).cuda()
     p256 = torch.from_numpy(synth.patches_u8(6, n_patches=1, size=256)).cuda()          # 64 x 64 maps (256-px patches): the WIDE tail form (208-row planes, three-stage ring, tap-major K like the implicit GEMM these maps take unfused)
     outs = {}
-    for tag, env in (("tail", {}), ("chain", {"SQ_RESNET_NO_TAIL": "1"}), ("chain_no_ds", {"SQ_RESNET_NO_TAIL": "1", "SQ_RESNET_NO_CHAIN_DS": "1"}),
+    for tag, env in (("tail", {}), ("no_chainw", {"SQ_RESNET_NO_CHAINW": "1"}), ("chain", {"SQ_RESNET_NO_TAIL": "1"}), ("chain_no_ds", {"SQ_RESNET_NO_TAIL": "1", "SQ_RESNET_NO_CHAIN_DS": "1"}),
                      ("no_dual", {"SQ_RESNET_NO_DUAL": "1"}), ("dual_everywhere", {"SQ_RESNET_NO_CHAIN": "1"}),
-                     ("plain", {"SQ_RESNET_NO_CHAIN": "1", "SQ_RESNET_NO_DUAL": "1"})):
-        for k in ("SQ_RESNET_NO_TAIL", "SQ_RESNET_NO_CHAIN_DS", "SQ_RESNET_NO_CHAIN", "SQ_RESNET_NO_DUAL"):
+                     ("plain", {"SQ_RESNET_NO_CHAIN": "1", "SQ_RESNET_NO_DUAL": "1", "SQ_RESNET_NO_CHAINW": "1"})):
+        for k in ("SQ_RESNET_NO_TAIL", "SQ_RESNET_NO_CHAIN_DS", "SQ_RESNET_NO_CHAIN", "SQ_RESNET_NO_DUAL", "SQ_RESNET_NO_CHAINW"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         outs[tag] = (m.extract_patches_u8(p), m.extract_patches_u8(p256))
     torch.cuda.synchronize()
     assert torch.isfinite(outs["tail"][0]).all()
-    for tag in ("tail", "chain", "chain_no_ds", "no_dual", "dual_everywhere"):
+    for tag in ("tail", "no_chainw", "chain", "chain_no_ds", "no_dual", "dual_everywhere"):
         assert torch.equal(outs[tag][0], outs["plain"][0]) and torch.equal(outs[tag][1], outs["plain"][1]), tag
