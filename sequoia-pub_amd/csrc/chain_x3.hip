@@ -33,6 +33,7 @@
 #include "x3_fmt.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 extern int g_dbg;                // sq_dbg_set key 1 (gemm.hip)
@@ -92,6 +93,7 @@ struct ChainX3Args {
     uint32_t w2_bytes;
     int W, HW;                                   // map width and pixels per image (square maps)
     int dbg;                                     // ablation switches (tools/chain_probe.py): 1 no stores, 2 no identity reads, 4 no 3x3, 8 no second product
+    int nt;                                      // identity reads and y stores carry the streaming (nt) policy (SQ_X3_NT)
 };
 
 template <int N2, bool F16, bool DS, bool TAIL, bool WIDE = false>
@@ -145,8 +147,10 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
     u32x4 rh[8], rl[8];
     auto load_res = [&](int u) {                   // identity chunk of row rsub + 8 u: 2 reads
         const int m = min(p0 + u * 8 + rsub, p.P - 1);      // rows past P repeat the last one (never stored): no branch around the read
-        rh[u] = *reinterpret_cast<const u32x4*>(p.res + (size_t)m * N1 + c8 * 8);
-        rl[u] = *reinterpret_cast<const u32x4*>(p.res + p.plRes + (size_t)m * N1 + c8 * 8);
+        const u32x4* qh = reinterpret_cast<const u32x4*>(p.res + (size_t)m * N1 + c8 * 8);
+        const u32x4* ql = reinterpret_cast<const u32x4*>(p.res + p.plRes + (size_t)m * N1 + c8 * 8);
+        if (p.nt) { rh[u] = __builtin_nontemporal_load(qh); rl[u] = __builtin_nontemporal_load(ql); }
+        else { rh[u] = *qh; rl[u] = *ql; }
     };
     constexpr int NEXTRA = 8;
     auto extra_reads = [&](int k) {                // group k of NEXTRA, 4 reads each
@@ -408,8 +412,10 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             *reinterpret_cast<u32x4*>(chunk) = hi;                  // rows past P: never stored, and their t1' rows neither
             *reinterpret_cast<u32x4*>(chunk + 16) = lo;
             if (m < p.P && !(p.dbg & 1)) {
-                *reinterpret_cast<u32x4*>(p.y + (size_t)m * N1 + c8 * 8) = hi;
-                *reinterpret_cast<u32x4*>(p.y + p.plY + (size_t)m * N1 + c8 * 8) = lo;
+                u32x4* qh = reinterpret_cast<u32x4*>(p.y + (size_t)m * N1 + c8 * 8);
+                u32x4* ql = reinterpret_cast<u32x4*>(p.y + p.plY + (size_t)m * N1 + c8 * 8);
+                if (p.nt) { __builtin_nontemporal_store(hi, qh); __builtin_nontemporal_store(lo, ql); }
+                else { *qh = hi; *ql = lo; }
             }
         }
     }
@@ -558,6 +564,7 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     a.w3_bytes = clamp(w3_bytes);
     a.xin = xin; a.plX = plX; a.wd = frag + FRAG_WD; a.bd = bd; a.csd = csd; a.wd_bytes = clamp(wd_bytes);
     a.t1 = t1; a.plT1 = plT1; a.w2 = frag + FRAG_W2; a.b2 = b2; a.cs2 = cs2; a.w2_bytes = (uint32_t)((FRAG - FRAG_W2) * 2); a.W = W; a.HW = HW; a.dbg = g_dbg;
+    { static int env_nt = -2; if (env_nt == -2) { const char* e = getenv("SQ_X3_NT"); env_nt = e ? atoi(e) : -1; } a.nt = env_nt > 0 ? 1 : 0; }       // default off (no gain measured in the pipeline)
     using I64 = std::integral_constant<int, 64>; using I128 = std::integral_constant<int, 128>;
     using T = std::true_type; using F = std::false_type;
     auto pick_tail = [&](auto n2c, auto f16c, auto dsc) {
