@@ -60,6 +60,11 @@ int sq_k_batch_sum(const float* x, float* out, int B, int ND, hipStream_t s);
 size_t sq_ln_bwd_ws_floats(int D);
 int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const float* dres, float* dx, bf16_t* dx_lp,
                      float* dg, float* db, float* ws, int R, int D, hipStream_t s, sq_colsum_jobs* defer = nullptr);
+// the same with dy / x / dres in fp32 or bf16 and an optional fp32 result (dx may be null when dx_lp is given): the lean bf16 training stream
+int sq_k_ln_rows_bwd_any(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* g, const void* dres, int dres_dtype,
+                         float* dx, bf16_t* dx_lp, float* dg, float* db, float* ws, int R, int D, hipStream_t s, sq_colsum_jobs* defer = nullptr);
+int sq_k_ln64_gelu_bwd_any(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* g, const float* b, void* dx, int out_dtype,
+                           float* dg, float* db, float* ws, int R, int C, hipStream_t s, sq_colsum_jobs* defer = nullptr);
 // backward of y = GELU(LN64(x)*g + b): dx (f32 or bf16 by out_dtype), dg/db [C].  ws >= ln_bwd_ws_floats(C)
 int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const float* b, void* dx, int out_dtype,
                        float* dg, float* db, float* ws, int R, int C, hipStream_t s, sq_colsum_jobs* defer = nullptr);

@@ -147,7 +147,7 @@ __global__ void bcast_rows_kernel(const float4* __restrict__ src, float scale, f
         const int d = (int)(i % (uint32_t)D4);
         float4 v = src[(size_t)b * D4 + d];
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-        dst[i] = v;
+        if (dst) dst[i] = v;
         if (dst_lp) dst_lp[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
     }
 }
@@ -160,10 +160,20 @@ __global__ void batch_sum_kernel(const float* __restrict__ x, float* __restrict_
     out[i] = acc;
 }
 
+// four consecutive elements of row-major [.., ld] data, fp32 or bf16 (wave-uniform switch): the lean bf16 training stream keeps
+// saved activations and the gradient stream in bf16 only
+__device__ __forceinline__ float4 ld4_any(const void* base, size_t elem_off, int c4, int is_bf16) {
+    if (is_bf16) {
+        const uint2 u = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + elem_off)[c4];
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off)[c4];
+}
+
 // one wave per row (grid-strided); lane owns float4 columns i*64+lane; per-block dg/db partials go to ws
 template <int MAXI>
-__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                          const float* __restrict__ g, const float* __restrict__ dres,
+__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const void* __restrict__ dy, int dy_bf16, const void* __restrict__ x, int x_bf16,
+                                                          const float* __restrict__ g, const void* __restrict__ dres, int dres_bf16,
                                                           float* __restrict__ dx, bf16_t* __restrict__ dx_lp,
                                                           float* __restrict__ ws, int R, int D) {
     const int lane = threadIdx.x & 63;
@@ -179,15 +189,13 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
         gg[i] = c < D4 ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int row = wave_global; row < R; row += nwaves) {
-        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
-        const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * D);
         float4 xv[MAXI], dv[MAXI];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int c = i * 64 + lane;
-            xv[i] = c < D4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            dv[i] = c < D4 ? dyr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[i] = c < D4 ? ld4_any(x, (size_t)row * D, c, x_bf16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[i] = c < D4 ? ld4_any(dy, (size_t)row * D, c, dy_bf16) : make_float4(0.f, 0.f, 0.f, 0.f);
             s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
         }
         const float mean = wave_sum(s) / (float)D;
@@ -224,10 +232,10 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
                 o.z = rstd * (dv[i].z - c1 - xv[i].z * c2);
                 o.w = rstd * (dv[i].w - c1 - xv[i].w * c2);
                 if (dres) {
-                    const float4 r4 = reinterpret_cast<const float4*>(dres + (size_t)row * D)[c];
+                    const float4 r4 = ld4_any(dres, (size_t)row * D, c, dres_bf16);
                     o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
                 }
-                reinterpret_cast<float4*>(dx + (size_t)row * D)[c] = o;
+                if (dx) reinterpret_cast<float4*>(dx + (size_t)row * D)[c] = o;
                 if (dx_lp) reinterpret_cast<uint2*>(dx_lp + (size_t)row * D)[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
             }
         }
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float* __restric
 
 // thread owns float4 column(s) (fixed), walks rows; 16 lanes = one 64-wide group
 template <int NCH, bool FAST>
-__global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const void* __restrict__ dy, int dy_bf16, const void* __restrict__ x, int x_bf16,
                                                             const float* __restrict__ g, const float* __restrict__ b,
                                                             void* __restrict__ dx, int out_bf16, float* __restrict__ ws,
                                                             int R, int C) {
@@ -274,8 +282,8 @@ __global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c4 = k * 256 + col0;
-            const float4 v = reinterpret_cast<const float4*>(x + (size_t)row * C)[c4];
-            const float4 d = reinterpret_cast<const float4*>(dy + (size_t)row * C)[c4];
+            const float4 v = ld4_any(x, (size_t)row * C, c4, x_bf16);
+            const float4 d = ld4_any(dy, (size_t)row * C, c4, dy_bf16);
             const float4 gg = reinterpret_cast<const float4*>(g)[c4], bb = reinterpret_cast<const float4*>(b)[c4];
             float s = (v.x + v.y) + (v.z + v.w);
 #pragma unroll
@@ -394,13 +402,20 @@ size_t sq_ln_bwd_ws_floats(int D) { return (size_t)LN_BWD_PARTIALS * 2 * D + sq_
 
 int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const float* dres, float* dx, bf16_t* dx_lp, float* dg,
                      float* db, float* ws, int R, int D, hipStream_t s, sq_colsum_jobs* defer) {
+    return sq_k_ln_rows_bwd_any(dy, SQ_F32, x, SQ_F32, g, dres, SQ_F32, dx, dx_lp, dg, db, ws, R, D, s, defer);
+}
+
+int sq_k_ln_rows_bwd_any(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* g, const void* dres, int dres_dtype,
+                         float* dx, bf16_t* dx_lp, float* dg, float* db, float* ws, int R, int D, hipStream_t s, sq_colsum_jobs* defer) {
     SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows_bwd: D=%d", D);
+    SQ_REQUIRE(dx || dx_lp, "ln_rows_bwd: no output");
+    const int dyb = dy_dtype == SQ_BF16, xb = x_dtype == SQ_BF16, drb = dres_dtype == SQ_BF16;
     int nblk = (R + 3) / 4;
     if (nblk > LN_BWD_PARTIALS) nblk = LN_BWD_PARTIALS;
     const dim3 grid(nblk), block(256);
-    if (D <= 1024) hipLaunchKernelGGL(ln_rows_bwd_kernel<4>, grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);
-    else if (D <= 2048) hipLaunchKernelGGL(ln_rows_bwd_kernel<8>, grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);
-    else hipLaunchKernelGGL(ln_rows_bwd_kernel<16>, grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);
+    if (D <= 1024) hipLaunchKernelGGL(ln_rows_bwd_kernel<4>, grid, block, 0, s, dy, dyb, x, xb, g, dres, drb, dx, dx_lp, ws, R, D);
+    else if (D <= 2048) hipLaunchKernelGGL(ln_rows_bwd_kernel<8>, grid, block, 0, s, dy, dyb, x, xb, g, dres, drb, dx, dx_lp, ws, R, D);
+    else hipLaunchKernelGGL(ln_rows_bwd_kernel<16>, grid, block, 0, s, dy, dyb, x, xb, g, dres, drb, dx, dx_lp, ws, R, D);
     SQ_LAUNCH_CHECK();
     // partial rows are [dg | db] of length 2D: one column-sum over nblk*4 partial rows, then split
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * D;
@@ -410,6 +425,12 @@ int sq_k_ln_rows_bwd(const float* dy, const float* x, const float* g, const floa
 
 int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const float* b, void* dx, int out_dtype, float* dg,
                        float* db, float* ws, int R, int C, hipStream_t s, sq_colsum_jobs* defer) {
+    return sq_k_ln64_gelu_bwd_any(dy, SQ_F32, x, SQ_F32, g, b, dx, out_dtype, dg, db, ws, R, C, s, defer);
+}
+
+int sq_k_ln64_gelu_bwd_any(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* g, const float* b, void* dx, int out_dtype,
+                           float* dg, float* db, float* ws, int R, int C, hipStream_t s, sq_colsum_jobs* defer) {
+    const int dyb = dy_dtype == SQ_BF16, xb = x_dtype == SQ_BF16;
     const int C16 = C / 4;
     SQ_REQUIRE(C % 64 == 0 && ((C16 <= 256 && 256 % C16 == 0) || C16 == 512 || C16 == 1024),
                "ln64_gelu_bwd: C=%d (nheads must be a power of two <= 64 for the training path)", C);
@@ -421,13 +442,13 @@ int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const fl
     const int ob = out_dtype == SQ_BF16;
     // bf16 gradients out: the 7-term erf (consistent with the forward kernel); fp32: erff
     if (ob) {
-        if (nch == 1) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<1, true>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
-        else if (nch == 2) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<2, true>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
-        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<4, true>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+        if (nch == 1) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<1, true>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
+        else if (nch == 2) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<2, true>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
+        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<4, true>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
     } else {
-        if (nch == 1) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<1, false>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
-        else if (nch == 2) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<2, false>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
-        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<4, false>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);
+        if (nch == 1) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<1, false>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
+        else if (nch == 2) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<2, false>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
+        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<4, false>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
     }
     SQ_LAUNCH_CHECK();
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * C;

@@ -46,6 +46,12 @@ void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base,
 int sq_launch_summary_fwd(const void* Xbar, const void* Ws, const float* bs, const float* lng, const float* lnb, const void* Wc,
                           const float* bc, float* Sm, void* Ts, float* Cs, int B, int D, int H, hipStream_t stream);
 
+// bf16 mode keeps the residual stream, the saved activations and the gradient stream in bf16 only (forward AND backward must
+// agree on it: the backward pass re-reads what the forward pass stored); SQ_VIS_FP32_STREAM=1: fp32 streams + bf16 operand copies
+inline bool sq_vis_lean_stream(int dtype) {
+    return dtype == SQ_BF16 && !sq_env_flag("SQ_VIS_FP32_STREAM");      // (read per call: tests flip it inside one process)
+}
+
 // dtype of the saved GELU pre-activations (U, P): the operand dtype; SQ_F32_PREACT=1 keeps fp32 (A/B knob)
 inline int sq_vis_preact_dtype(int dtype) {
     static const int force32 = sq_env_flag("SQ_F32_PREACT") ? 1 : 0;

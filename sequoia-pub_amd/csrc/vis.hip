@@ -162,7 +162,10 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
     // products of a layer then read and write 2-byte rows instead of 4-byte rows plus a 2-byte copy, LayerNorm and the
     // token mean read half the bytes -- about a third of a layer's HBM traffic.  The fp32 stream stays for training
     // (save_for_backward), for fp32 mode, and on request (SQ_VIS_FP32_STREAM=1).
-    const bool stream16 = lp && !save && !sq_env_flag("SQ_VIS_FP32_STREAM");
+    // Training in bf16 mode (save_for_backward) does the same since round 5 -- BASELINE config 2 is "forward+backward bf16": the
+    // layer inputs, X1 and the pre-LayerNorm(64) tensor F are stored in bf16 only (what the backward pass re-reads), fp32 master
+    // weights and AdamW state stay.  SQ_VIS_FP32_STREAM=1 brings the fp32 stream back for both.
+    const bool stream16 = sq_vis_lean_stream(dtype);
     SqSideStream* fs = (lp && !sq_env_flag("SQ_FWD_ONE_STREAM")) ? sq_side_stream(1, 4 * SQ_MAX_DEPTH) : nullptr;
     hipStream_t s2 = fs ? fs->stream : st;
     int ev_next = 0;
@@ -210,7 +213,7 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             GemmArgs g; g.A = Xin_t; g.lda = D; g.a_bytes = (size_t)M * D * es;
             g.B = W(L.f_w); g.ldb = D; g.b_bytes = Wrem(L.f_w); g.bias = Pf(L.f_b);
             g.ln64_g = Pf(L.lnf_g); g.ln64_b = Pf(L.lnf_b); g.act = SQ_ACT_GELU;
-            if (save) { g.Cpre = w.F[s]; g.pre_dtype = SQ_F32; g.ldpre = HD; }
+            if (save) { g.Cpre = w.F[s]; g.pre_dtype = stream16 ? SQ_BF16 : SQ_F32; g.ldpre = HD; }
             g.C = w.Lf[s]; g.out_dtype = dtype; g.ldc = HD; g.M = M; g.N = HD; g.K = D;
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
@@ -251,7 +254,7 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
         }
     }
     const float* Xfin = w.Xin[save ? c->depth : 0];
-    if (int e = sq_k_token_mean_any(stream16 ? w.Xin_lp[0] : (const void*)Xfin, stream16 ? SQ_BF16 : SQ_F32, w.xm, nullptr, B, N, D, st)) return e;
+    if (int e = sq_k_token_mean_any(stream16 ? w.Xin_lp[save ? c->depth : 0] : (const void*)Xfin, stream16 ? SQ_BF16 : SQ_F32, w.xm, nullptr, B, N, D, st)) return e;
     if (head_in)        // the caller applies the (linear) head itself, e.g. after averaging over windows: LN output in fp32
         return sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), head_in, SQ_F32, B, D, nullptr, nullptr, st);
     if (int e = sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), w.xn, dtype, B, D, nullptr, nullptr, st)) return e;

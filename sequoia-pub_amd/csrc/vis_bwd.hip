@@ -160,6 +160,10 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
     const int Gp = (int)sq_align_up(G, 8), Bp = (int)sq_align_up((size_t)B, 8);
     const int es = sq_dtype_size(dtype);
     const bool lp = dtype == SQ_BF16;
+    // lean bf16 stream (vis.h): X1 and F were saved in bf16, and the gradient stream between the layers (dXin, dX1, dY, dLf) is
+    // bf16 only -- no fp32 running gradient beside the operand copies
+    const bool lean = sq_vis_lean_stream(dtype);
+    const int sdt = lean ? SQ_BF16 : SQ_F32;       // dtype of the stream tensors
     const char* wbase = lp ? (const char*)params_lp : (const char*)params;
     auto W = [&](int64_t off) { return (const void*)(wbase + (size_t)off * es); };
     auto Pf = [&](int64_t off) { return params + off; };
@@ -221,7 +225,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
                          b.red_ws, B, D, st));
     RUN(bucket_done(0));
     const int top = c->depth - 1;
-    RUN(sq_k_bcast_rows(b.dxm, 1.0f / (float)N, b.dXa, lp ? (bf16_t*)b.lg[top].dXin_lp : nullptr, B, N, D, st));
+    RUN(sq_k_bcast_rows(b.dxm, 1.0f / (float)N, lean ? nullptr : b.dXa, lp ? (bf16_t*)b.lg[top].dXin_lp : nullptr, B, N, D, st));
 
     // ---- second stream for the weight-gradient products (bf16 mode).  They are off the critical path (nothing in
     // the dX chain reads a dW), and a GEMM of this size cannot overlap its own memory-bound epilogue with its MFMA
@@ -317,10 +321,11 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         }
         RUN(ready());
         { GemmArgs g = gemm_tn(lg.dU, D, w.Y[l], D, Gp_(L.ff1_w), D, D, D, M); g.colsum_a = Gp_(L.ff1_b); RUN(queue_tn(g)); }
-        { GemmArgs g = gemm(lg.dU, D, b.wt[l].ff1, D, b.dY, D, M, D, D); RUN(sq_launch_gemm(g, dtype, st)); }
+        { GemmArgs g = gemm(lg.dU, D, b.wt[l].ff1, D, b.dY, D, M, D, D); if (lean) g.out_dtype = SQ_BF16; RUN(sq_launch_gemm(g, dtype, st)); }
         // dX1 = dX2 + dLN(dY)
-        RUN(sq_k_ln_rows_bwd(b.dY, w.X1[l], Pf(L.ffln_g), dXcur, dXoth, lp ? (bf16_t*)lg.dX1_lp : nullptr, Gp_(L.ffln_g),
-                             Gp_(L.ffln_b), b.part_ws[0], M, D, st, defer));
+        RUN(sq_k_ln_rows_bwd_any(b.dY, sdt, w.X1[l], sdt, Pf(L.ffln_g), lean ? (const void*)lg.dXin_lp : (const void*)dXcur, sdt,
+                                 lean ? nullptr : dXoth, lp ? (bf16_t*)lg.dX1_lp : nullptr, Gp_(L.ffln_g),
+                                 Gp_(L.ffln_b), b.part_ws[0], M, D, st, defer));
         float* dX1 = dXoth;
 
         // ---------------- projection: X1 = O Wp^T + bp + X ----------------
@@ -373,9 +378,10 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
             GemmArgs g = gemm(lg.dP, HD, b.wt[l].wc_lf, SQ_HEAD_DIM, b.dLf, HD, M, SQ_HEAD_DIM, SQ_HEAD_DIM);
             g.a_bytes = (size_t)M * HD * es; g.b_bytes = (size_t)H * 64 * 64 * es;
             g.batch = H; g.sA = SQ_HEAD_DIM; g.sB = SQ_HEAD_DIM * SQ_HEAD_DIM; g.sC = SQ_HEAD_DIM;
+            if (lean) g.out_dtype = SQ_BF16;
             RUN(sq_launch_gemm(g, dtype, st));
         }
-        RUN(sq_k_ln64_gelu_bwd(b.dLf, w.F[l], Pf(L.lnf_g), Pf(L.lnf_b), lg.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.part_ws[2], M, HD, st, defer));
+        RUN(sq_k_ln64_gelu_bwd_any(b.dLf, sdt, w.F[l], sdt, Pf(L.lnf_g), Pf(L.lnf_b), lg.dF, dtype, Gp_(L.lnf_g), Gp_(L.lnf_b), b.part_ws[2], M, HD, st, defer));
         RUN(ready());       // (the side stream has by now also waited for every summary-branch gradient of this layer)
         { GemmArgs g = gemm_tn(lg.dF, HD, w.Xin_lp[l], D, Gp_(L.f_w), D, HD, D, M); g.colsum_a = Gp_(L.f_b); RUN(queue_tn(g)); RUN(flush_tn()); }
         if (ev_xbar) SQ_HIP_CHECK(hipStreamWaitEvent(st, ev_xbar, 0));
@@ -387,6 +393,10 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
             GemmArgs g = gemm(lg.dF, HD, b.wt[l].f, HD, dXcur, D, M, D, HD);
             g.res = dX1; g.ldres = D; g.rowbias = b.dXbar; g.ldrb = D; g.rows_per_group = N;
             g.C2 = (lp && l > 0) ? (bf16_t*)b.lg[l - 1].dXin_lp : nullptr; g.ldc2 = D;
+            if (lean) {         // the residual is the bf16 dX1; the result goes straight into the next layer's bf16 dXin (layer 0: fp32, for the position-embedding sum)
+                g.res = lg.dX1_lp; g.res_dtype = SQ_BF16; g.C2 = nullptr;
+                if (l > 0) { g.C = b.lg[l - 1].dXin_lp; g.out_dtype = SQ_BF16; }
+            }
             RUN(sq_launch_gemm(g, dtype, st));
         }
         // fp32 keeps the gradient in dXcur for the next layer (read as its dXin); dX1 lived in dXoth: no swap needed

@@ -143,6 +143,11 @@ class FusedTrainStep:
         # a side stream as soon as the backward pass has recorded its event.  SQ_FORCE_BUCKETS=1 exercises the
         # same path on a single rank.
         self.overlap = world_size > 1 or os.environ.get("SQ_FORCE_BUCKETS") == "1"
+        # AdamW per bucket on the communication stream, as each bucket becomes final (SQ_ADAMW_BUCKETS=1; also switches the bucket
+        # path on for one rank).  Opt-in: measured SLOWER on one MI355X -- the 1.6 GB HBM-bound update running beside the backward
+        # pass's products costs them more than the 0.28 ms pass it removes (config 2: 3.26 ms without, 3.33 ms with)
+        self.adamw_buckets = os.environ.get("SQ_ADAMW_BUCKETS", "0") == "1" and model._C_BWD == "sq_vis_backward"
+        self.overlap = self.overlap or self.adamw_buckets
         if grad_exchange is None:
             grad_exchange = os.environ.get("SQ_DDP_GRAD_EXCHANGE") or ("bf16" if model.compute_dtype == _lib.SQ_BF16 else "fp32")
         if grad_exchange not in ("bf16", "fp32"):
@@ -156,8 +161,8 @@ class FusedTrainStep:
             self.comm_stream = torch.cuda.Stream(device=dev)
             self.events = [torch.cuda.Event() for _ in self.buckets]
             n_el = sum(hi - lo for lo, hi in self.buckets)
-            self.exchange_bytes_per_step = n_el * (2 if grad_exchange == "bf16" else 4)
-            if grad_exchange == "bf16":
+            self.exchange_bytes_per_step = (n_el * (2 if grad_exchange == "bf16" else 4)) if world_size > 1 else 0
+            if grad_exchange == "bf16" and world_size > 1:      # (one rank exchanges nothing: its gradient is never rounded)
                 self._wire = torch.empty(model.flat.numel(), dtype=torch.bfloat16, device=dev)     # bucket i travels as _wire[lo:hi]
             with torch.cuda.device(dev):
                 for e in self.events:
@@ -204,7 +209,10 @@ class FusedTrainStep:
                 gflat, _ = vis_backward(m, gpred, B, False, bucket_events=self.events)
                 if sample:
                     tb1.record(main)
-            reduce_ = dist.is_available() and dist.is_initialized()
+            reduce_ = dist.is_available() and dist.is_initialized() and self.world > 1
+            if self.adamw_buckets:
+                self.step_count += 1
+                lp = m._params_lp()
             for i, ((lo, hi), ev) in enumerate(zip(self.buckets, self.events)):
                 self.comm_stream.wait_event(ev)
                 if not empty and sample and i == 0:
@@ -219,10 +227,20 @@ class FusedTrainStep:
                             if reduce_:
                                 dist.all_reduce(self._wire[lo:hi], op=dist.ReduceOp.SUM)
                             _lib.check(_lib.lib().sq_cast_bf16_to_f32(_lib.ptr(self._wire[lo:hi]), _lib.ptr(gflat[lo:hi]), hi - lo, cs))
+                if not self.adamw_buckets:
+                    continue
+                # the bucket's AdamW update (element-wise: identical to one pass over the flat buffer) behind its exchange
+                with torch.cuda.stream(self.comm_stream), torch.no_grad():
+                    _lib.check(_lib.lib().sq_adamw_step(_lib.ptr(m.flat[lo:hi]), _lib.ptr(gflat[lo:hi]), _lib.ptr(self.exp_avg[lo:hi]),
+                                                        _lib.ptr(self.exp_avg_sq[lo:hi]), _lib.ptr(lp[lo:hi]) if lp is not None else None,
+                                                        hi - lo, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, 1.0,
+                                                        _lib.stream_ptr(dev)))
             if not empty and sample:
                 tc1.record(self.comm_stream)
                 self._tm["pending"] = (tb0, tb1, tc0, tc1)
             main.wait_stream(self.comm_stream)
+            if self.adamw_buckets:
+                return None if empty else (loss, pred, mets)
         self.step_count += 1
         lp = m._params_lp()
         with torch.no_grad():

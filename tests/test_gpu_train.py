@@ -324,3 +324,38 @@ def test_helper_streams_do_not_change_results(monkeypatch):
     l_one, p_one = run()
     assert l_multi == l_one
     assert torch.equal(p_multi, p_one)
+
+
+def test_bf16_training_follows_the_fp32_oracle_for_twenty_steps():
+    """The bf16 compute mode must TRAIN like the fp32 reference, not only match it for one step: twenty AdamW steps (lr 1e-3,
+    weight_decay 0, src/main.py:180-183) of the BASELINE config-2 model on one fixed batch of 32 slides -- the fused HIP step in
+    bf16 (bf16 operands and saved activations, fp32 master weights and moments) against CPU fp32 autograd + the restated AdamW
+    (oracle/vis_oracle.py).  The loss must stay within 1 % of the reference's at EVERY step."""
+    from collections import OrderedDict
+    _lib.require_gpu()
+    cfg = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=21), seed=3)
+    B, steps = 32, 20
+    x = torch.from_numpy(synth.cluster_tokens(31, B, 1024))
+    y = torch.from_numpy(synth.rna_targets(9, B))
+    m = ViS(**cfg, device="cuda:0", compute_dtype="bf16")
+    m.load_state_dict(sd)
+    m.to("cuda:0")
+    st = sq_train.FusedTrainStep(m, lr=1e-3)
+    xg, yg = x.cuda(), y.cuda()
+    got = [float(st.step(xg, yg)[0]) for _ in range(steps)]
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(32, os.cpu_count()))
+    params = OrderedDict((k, v.clone()) for k, v in sd.items())
+    m1 = OrderedDict((k, torch.zeros_like(v)) for k, v in sd.items())
+    m2 = OrderedDict((k, torch.zeros_like(v)) for k, v in sd.items())
+    ref = []
+    for t in range(1, steps + 1):
+        loss, _, grads = vis_oracle.vis_loss_and_grads(params, x, y)
+        ref.append(float(loss))
+        vis_oracle.adamw_step(params, grads, m1, m2, t, lr=1e-3)
+    gaps = [abs(a - b) / b for a, b in zip(got, ref)]
+    print("20-step trajectory bf16 vs fp32 oracle: loss " + " ".join(f"{a:.4f}/{b:.4f}" for a, b in zip(got[::4], ref[::4])) +
+          f"; worst relative gap {max(gaps):.2e} at step {int(np.argmax(gaps)) + 1}")
+    assert ref[-1] < 0.9 * ref[0], "the reference itself must be learning on this batch"
+    assert max(gaps) < 1e-2, gaps
