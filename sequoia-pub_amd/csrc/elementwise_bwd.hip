@@ -162,8 +162,9 @@ __global__ void batch_sum_kernel(const float* __restrict__ x, float* __restrict_
 
 // four consecutive elements of row-major [.., ld] data, fp32 or bf16 (wave-uniform switch): the lean bf16 training stream keeps
 // saved activations and the gradient stream in bf16 only
-__device__ __forceinline__ float4 ld4_any(const void* base, size_t elem_off, int c4, int is_bf16) {
-    if (is_bf16) {
+template <bool is_bf16>
+__device__ __forceinline__ float4 ld4_any(const void* base, size_t elem_off, int c4) {
+    if constexpr (is_bf16) {
         const uint2 u = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + elem_off)[c4];
         return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
     }
@@ -171,9 +172,11 @@ __device__ __forceinline__ float4 ld4_any(const void* base, size_t elem_off, int
 }
 
 // one wave per row (grid-strided); lane owns float4 columns i*64+lane; per-block dg/db partials go to ws
-template <int MAXI>
-__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const void* __restrict__ dy, int dy_bf16, const void* __restrict__ x, int x_bf16,
-                                                          const float* __restrict__ g, const void* __restrict__ dres, int dres_bf16,
+// LEAN: dy, x and dres are bf16 (the lean training stream); a compile-time switch -- a run-time one puts every load behind its own
+// branch and the loads of a row no longer go out together (measured: 22.8 -> 25.4 us although the kernel read fewer bytes)
+template <int MAXI, bool LEAN>
+__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                          const float* __restrict__ g, const void* __restrict__ dres,
                                                           float* __restrict__ dx, bf16_t* __restrict__ dx_lp,
                                                           float* __restrict__ ws, int R, int D) {
     const int lane = threadIdx.x & 63;
@@ -194,8 +197,8 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const void* __restrict
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int c = i * 64 + lane;
-            xv[i] = c < D4 ? ld4_any(x, (size_t)row * D, c, x_bf16) : make_float4(0.f, 0.f, 0.f, 0.f);
-            dv[i] = c < D4 ? ld4_any(dy, (size_t)row * D, c, dy_bf16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[i] = c < D4 ? ld4_any<LEAN>(x, (size_t)row * D, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[i] = c < D4 ? ld4_any<LEAN>(dy, (size_t)row * D, c) : make_float4(0.f, 0.f, 0.f, 0.f);
             s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
         }
         const float mean = wave_sum(s) / (float)D;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const void* __restrict
                 o.z = rstd * (dv[i].z - c1 - xv[i].z * c2);
                 o.w = rstd * (dv[i].w - c1 - xv[i].w * c2);
                 if (dres) {
-                    const float4 r4 = ld4_any(dres, (size_t)row * D, c, dres_bf16);
+                    const float4 r4 = ld4_any<LEAN>(dres, (size_t)row * D, c);
                     o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
                 }
                 if (dx) reinterpret_cast<float4*>(dx + (size_t)row * D)[c] = o;
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const void* __restrict
 }
 
 // thread owns float4 column(s) (fixed), walks rows; 16 lanes = one 64-wide group
-template <int NCH, bool FAST>
-__global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const void* __restrict__ dy, int dy_bf16, const void* __restrict__ x, int x_bf16,
+template <int NCH, bool FAST, bool LEAN>
+__global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ b,
                                                             void* __restrict__ dx, int out_bf16, float* __restrict__ ws,
                                                             int R, int C) {
@@ -282,8 +285,8 @@ __global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const void* __restri
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c4 = k * 256 + col0;
-            const float4 v = ld4_any(x, (size_t)row * C, c4, x_bf16);
-            const float4 d = ld4_any(dy, (size_t)row * C, c4, dy_bf16);
+            const float4 v = ld4_any<LEAN>(x, (size_t)row * C, c4);
+            const float4 d = ld4_any<LEAN>(dy, (size_t)row * C, c4);
             const float4 gg = reinterpret_cast<const float4*>(g)[c4], bb = reinterpret_cast<const float4*>(b)[c4];
             float s = (v.x + v.y) + (v.z + v.w);
 #pragma unroll
@@ -319,6 +322,183 @@ __global__ __launch_bounds__(256) void ln64_gelu_bwd_kernel(const void* __restri
         const int c4 = k * 256 + col0;
         reinterpret_cast<float4*>(ws + prow * 2 * C)[c4] = ag[k];
         reinterpret_cast<float4*>(ws + prow * 2 * C + C)[c4] = ab[k];
+    }
+}
+
+
+// ---- lean (bf16 stream) forms of the two LayerNorm backward kernels: 16-byte accesses (8 columns per lane), 512-thread blocks and ONE
+// partial [dg | db] row per block, so that 512 partial rows no longer mean 8 waves per CU.  The generic kernels above, fed bf16 rows
+// through 8-byte loads, got SLOWER than on fp32 rows (22.8 -> 28.2 us, 13.0 -> 21.4 us): with <= 512 blocks of 4 waves they are bound
+// by the latency of one row at a time per wave, not by bytes.
+__device__ __forceinline__ void unpack8(const u32x4& u, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(u[e] << 16); v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+    return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+}
+
+// one wave per row; lane owns the 8-column chunks i * 64 + lane
+template <int MAXC>
+__global__ __launch_bounds__(512) void ln_rows_bwd_lean_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ g,
+                                                               const bf16_t* __restrict__ dres, float* __restrict__ dx, bf16_t* __restrict__ dx_lp,
+                                                               float* __restrict__ ws, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D8 = D >> 3;
+    float ag[MAXC][8], ab[MAXC][8], gg[MAXC][8];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = i * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; gg[i][e] = c < D8 ? g[c * 8 + e] : 0.f; }
+    }
+    // (requesting the next row's pieces before this row is worked on was tried: 20.9 -> 24.7 us)
+    for (int row = blockIdx.x * 8 + wave; row < R; row += gridDim.x * 8) {
+        const size_t ro = (size_t)row * D;
+        u32x4 xr[MAXC], dr[MAXC], rr[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = i * 64 + lane;
+            const bool ok = c < D8;
+            xr[i] = ok ? *reinterpret_cast<const u32x4*>(x + ro + c * 8) : u32x4{0, 0, 0, 0};
+            dr[i] = ok ? *reinterpret_cast<const u32x4*>(dy + ro + c * 8) : u32x4{0, 0, 0, 0};
+            rr[i] = (ok && dres) ? *reinterpret_cast<const u32x4*>(dres + ro + c * 8) : u32x4{0, 0, 0, 0};
+        }
+        float xv[MAXC][8], dv[MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            unpack8(xr[i], xv[i]); unpack8(dr[i], dv[i]);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) s += xv[i][e] + xv[i][e + 1];
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            if (i * 64 + lane < D8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xv[i][e] -= mean; q += xv[i][e] * xv[i][e]; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + LN_EPS);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xv[i][e] *= rstd;                                        // xhat
+                ag[i][e] += dv[i][e] * xv[i][e];
+                ab[i][e] += dv[i][e];
+                dv[i][e] *= gg[i][e];                                    // d xhat
+                c1 += dv[i][e];
+                c2 += dv[i][e] * xv[i][e];
+            }
+        c1 = wave_sum(c1) / (float)D;
+        c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = i * 64 + lane;
+            if (c < D8) {
+                float o[8], r8[8];
+                unpack8(rr[i], r8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dv[i][e] - c1 - xv[i][e] * c2) + r8[e];
+                if (dx) {
+                    reinterpret_cast<float4*>(dx + ro + c * 8)[0] = make_float4(o[0], o[1], o[2], o[3]);
+                    reinterpret_cast<float4*>(dx + ro + c * 8)[1] = make_float4(o[4], o[5], o[6], o[7]);
+                }
+                if (dx_lp) *reinterpret_cast<u32x4*>(dx_lp + ro + c * 8) = pack8(o);
+            }
+        }
+    }
+    // one partial row [dg | db] per block: waves 1..7 hand their sums to wave 0 through LDS, added in wave order
+    __shared__ float red[7][2][512];
+    float* wg = ws + (size_t)blockIdx.x * 2 * D;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        if (wave > 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[wave - 1][0][lane * 8 + e] = ag[i][e]; red[wave - 1][1][lane * 8 + e] = ab[i][e]; }
+        }
+        __syncthreads();
+        const int c = i * 64 + lane;
+        if (wave == 0 && c < D8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = ag[i][e], b = ab[i][e];
+#pragma unroll
+                for (int w = 0; w < 7; ++w) { a += red[w][0][lane * 8 + e]; b += red[w][1][lane * 8 + e]; }
+                wg[c * 8 + e] = a; wg[D + c * 8 + e] = b;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// thread owns 8 fixed columns and walks rows; 8 lanes = one 64-wide group; 512 / (C / 8) rows per block iteration
+template <bool FAST>
+__global__ __launch_bounds__(512) void ln64_gelu_bwd_lean_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ b, void* __restrict__ dx, int out_bf16,
+                                                                 float* __restrict__ ws, int R, int C) {
+    const int tpr = C >> 3, rpi = 512 / tpr;
+    const int rsub = threadIdx.x / tpr, col = (threadIdx.x % tpr) * 8;
+    float ag[8], ab[8], gg[8], bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; gg[e] = g[col + e]; bb[e] = b[col + e]; }
+    for (int row = blockIdx.x * rpi + rsub; row < R; row += gridDim.x * rpi) {
+        const size_t ro = (size_t)row * C + col;
+        float v[8], d[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + ro), v);
+        unpack8(*reinterpret_cast<const u32x4*>(dy + ro), d);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) s += v[e] + v[e + 1];
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.0f / 64.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
+        float h[8], c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] *= rstd;                                                // xhat
+            const float z = d[e] * sq_gelu_grad<FAST>(v[e] * gg[e] + bb[e]);
+            ag[e] += z * v[e]; ab[e] += z;
+            h[e] = z * gg[e];                                            // d xhat
+            c1 += h[e]; c2 += h[e] * v[e];
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+        c1 *= (1.0f / 64.0f); c2 *= (1.0f / 64.0f);
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = rstd * (h[e] - c1 - v[e] * c2);
+        if (out_bf16) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(dx) + ro) = pack8(o8);
+        else {
+            reinterpret_cast<float4*>(reinterpret_cast<float*>(dx) + ro)[0] = make_float4(o8[0], o8[1], o8[2], o8[3]);
+            reinterpret_cast<float4*>(reinterpret_cast<float*>(dx) + ro)[1] = make_float4(o8[4], o8[5], o8[6], o8[7]);
+        }
+    }
+    // one partial row per block: row slots 1.. hand their sums to slot 0 through LDS, added in slot order
+    extern __shared__ float red64[];              // [(rpi - 1)][2][C]
+    if (rsub > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red64[((size_t)(rsub - 1) * 2) * C + col + e] = ag[e]; red64[((size_t)(rsub - 1) * 2 + 1) * C + col + e] = ab[e]; }
+    }
+    __syncthreads();
+    if (rsub == 0) {
+        float* wg = ws + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = ag[e], bsum = ab[e];
+            for (int w = 0; w < rpi - 1; ++w) { a += red64[((size_t)w * 2) * C + col + e]; bsum += red64[((size_t)w * 2 + 1) * C + col + e]; }
+            wg[col + e] = a; wg[C + col + e] = bsum;
+        }
     }
 }
 
@@ -409,13 +589,30 @@ int sq_k_ln_rows_bwd_any(const void* dy, int dy_dtype, const void* x, int x_dtyp
                          float* dx, bf16_t* dx_lp, float* dg, float* db, float* ws, int R, int D, hipStream_t s, sq_colsum_jobs* defer) {
     SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows_bwd: D=%d", D);
     SQ_REQUIRE(dx || dx_lp, "ln_rows_bwd: no output");
-    const int dyb = dy_dtype == SQ_BF16, xb = x_dtype == SQ_BF16, drb = dres_dtype == SQ_BF16;
+    const bool lean = dy_dtype == SQ_BF16;
+    SQ_REQUIRE((x_dtype == SQ_BF16) == lean && (!dres || (dres_dtype == SQ_BF16) == lean), "ln_rows_bwd: dy, x and dres must share one dtype (all fp32 or all bf16)");
+    if (lean && D % 8 == 0) {
+        int nb = (R + 7) / 8;
+        if (nb > LN_BWD_PARTIALS) nb = LN_BWD_PARTIALS;
+        const bf16_t* dyb = (const bf16_t*)dy; const bf16_t* xb = (const bf16_t*)x; const bf16_t* rb = (const bf16_t*)dres;
+        if (D <= 1024) hipLaunchKernelGGL(ln_rows_bwd_lean_kernel<2>, dim3(nb), dim3(512), 0, s, dyb, xb, g, rb, dx, dx_lp, ws, R, D);
+        else if (D <= 2048) hipLaunchKernelGGL(ln_rows_bwd_lean_kernel<4>, dim3(nb), dim3(512), 0, s, dyb, xb, g, rb, dx, dx_lp, ws, R, D);
+        else hipLaunchKernelGGL(ln_rows_bwd_lean_kernel<8>, dim3(nb), dim3(512), 0, s, dyb, xb, g, rb, dx, dx_lp, ws, R, D);
+        SQ_LAUNCH_CHECK();
+        float* cs = ws + (size_t)LN_BWD_PARTIALS * 2 * D;
+        if (defer) return sq_colsum_jobs_add(defer, ws, nb, 2 * D, 2 * D, dg, db, D);
+        return colsum_impl(ws, SQ_F32, nb, 2 * D, 2 * D, cs, dg, s, db, D);
+    }
     int nblk = (R + 3) / 4;
     if (nblk > LN_BWD_PARTIALS) nblk = LN_BWD_PARTIALS;
     const dim3 grid(nblk), block(256);
-    if (D <= 1024) hipLaunchKernelGGL(ln_rows_bwd_kernel<4>, grid, block, 0, s, dy, dyb, x, xb, g, dres, drb, dx, dx_lp, ws, R, D);
-    else if (D <= 2048) hipLaunchKernelGGL(ln_rows_bwd_kernel<8>, grid, block, 0, s, dy, dyb, x, xb, g, dres, drb, dx, dx_lp, ws, R, D);
-    else hipLaunchKernelGGL(ln_rows_bwd_kernel<16>, grid, block, 0, s, dy, dyb, x, xb, g, dres, drb, dx, dx_lp, ws, R, D);
+#define SQ_LNB(MAXI)                                                                                                                \
+    do {                                                                                                                            \
+        if (lean) hipLaunchKernelGGL((ln_rows_bwd_kernel<MAXI, true>), grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);      \
+        else hipLaunchKernelGGL((ln_rows_bwd_kernel<MAXI, false>), grid, block, 0, s, dy, x, g, dres, dx, dx_lp, ws, R, D);         \
+    } while (0)
+    if (D <= 1024) SQ_LNB(4); else if (D <= 2048) SQ_LNB(8); else SQ_LNB(16);
+#undef SQ_LNB
     SQ_LAUNCH_CHECK();
     // partial rows are [dg | db] of length 2D: one column-sum over nblk*4 partial rows, then split
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * D;
@@ -430,26 +627,38 @@ int sq_k_ln64_gelu_bwd(const float* dy, const float* x, const float* g, const fl
 
 int sq_k_ln64_gelu_bwd_any(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* g, const float* b, void* dx, int out_dtype,
                            float* dg, float* db, float* ws, int R, int C, hipStream_t s, sq_colsum_jobs* defer) {
-    const int dyb = dy_dtype == SQ_BF16, xb = x_dtype == SQ_BF16;
+    const bool lean = dy_dtype == SQ_BF16;
+    SQ_REQUIRE((x_dtype == SQ_BF16) == lean, "ln64_gelu_bwd: dy and x must share one dtype");
     const int C16 = C / 4;
     SQ_REQUIRE(C % 64 == 0 && ((C16 <= 256 && 256 % C16 == 0) || C16 == 512 || C16 == 1024),
                "ln64_gelu_bwd: C=%d (nheads must be a power of two <= 64 for the training path)", C);
+    const int ob = out_dtype == SQ_BF16;
+    if (lean && C >= 64 && C <= 4096 && 512 % (C / 8) == 0) {
+        const int rpi_l = 512 / (C / 8);
+        int nb = (R + rpi_l - 1) / rpi_l;
+        if (nb > LN_BWD_PARTIALS) nb = LN_BWD_PARTIALS;
+        const size_t sh = (size_t)(rpi_l - 1) * 2 * C * 4;
+        if (ob) hipLaunchKernelGGL(ln64_gelu_bwd_lean_kernel<true>, dim3(nb), dim3(512), sh, s, (const bf16_t*)dy, (const bf16_t*)x, g, b, dx, ob, ws, R, C);
+        else hipLaunchKernelGGL(ln64_gelu_bwd_lean_kernel<false>, dim3(nb), dim3(512), sh, s, (const bf16_t*)dy, (const bf16_t*)x, g, b, dx, ob, ws, R, C);
+        SQ_LAUNCH_CHECK();
+        float* cs = ws + (size_t)LN_BWD_PARTIALS * 2 * C;
+        if (defer) return sq_colsum_jobs_add(defer, ws, nb, 2 * C, 2 * C, dg, db, C);
+        return colsum_impl(ws, SQ_F32, nb, 2 * C, 2 * C, cs, dg, s, db, C);
+    }
     const int nch = C16 <= 256 ? 1 : C16 / 256;
     const int rpi = C16 <= 256 ? 256 / C16 : 1;
     int nblk = (R + rpi - 1) / rpi;
     if (nblk * rpi > LN_BWD_PARTIALS) nblk = LN_BWD_PARTIALS / rpi;
     const dim3 grid(nblk), block(256);
-    const int ob = out_dtype == SQ_BF16;
     // bf16 gradients out: the 7-term erf (consistent with the forward kernel); fp32: erff
-    if (ob) {
-        if (nch == 1) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<1, true>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
-        else if (nch == 2) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<2, true>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
-        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<4, true>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
-    } else {
-        if (nch == 1) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<1, false>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
-        else if (nch == 2) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<2, false>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
-        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<4, false>), grid, block, 0, s, dy, dyb, x, xb, g, b, dx, ob, ws, R, C);
-    }
+#define SQ_L64(NCH, FAST)                                                                                                            \
+    do {                                                                                                                            \
+        if (lean) hipLaunchKernelGGL((ln64_gelu_bwd_kernel<NCH, FAST, true>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);     \
+        else hipLaunchKernelGGL((ln64_gelu_bwd_kernel<NCH, FAST, false>), grid, block, 0, s, dy, x, g, b, dx, ob, ws, R, C);        \
+    } while (0)
+    if (ob) { if (nch == 1) SQ_L64(1, true); else if (nch == 2) SQ_L64(2, true); else SQ_L64(4, true); }
+    else { if (nch == 1) SQ_L64(1, false); else if (nch == 2) SQ_L64(2, false); else SQ_L64(4, false); }
+#undef SQ_L64
     SQ_LAUNCH_CHECK();
     float* cs_ws = ws + (size_t)LN_BWD_PARTIALS * 2 * C;
     if (defer && nblk * rpi <= 512) return sq_colsum_jobs_add(defer, ws, nblk * rpi, 2 * C, 2 * C, dg, db, C);
