@@ -206,51 +206,94 @@ def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
     return roof, recs
 
 
-def measure_traffic(roof, args):
-    """--measure-traffic: HBM-side bytes per launch of the line's dominant kernel from the PMC counters of THIS build, in place of
-    the figure of the committed pass: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC slots) over one small
-    step of the same workload in child processes, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-byte
-    request on gfx950: doubled; KiB units).  Covers the kernel classes whose (symbol, grid) can be derived from their name: the
-    halo-staged 3x3 of the split modes (the headline's dominant class) and the plain split-mode products."""
+def _kernel_of_class(name):
+    """(kernel symbol substring, grid size in threads) of a profiled kernel class of the split-mode ResNet, from its name; None if
+    the class is not one whose launch geometry follows from the name."""
+    import re
+    m = re.match(r"(conv|gemm)_(f16x3|bf16x3)_M(\d+)_N(\d+)_K(\d+)$", name)
+    if m:
+        kind, f16, M, N, K = m.group(1), m.group(2) == "f16x3", int(m.group(3)), int(m.group(4)), int(m.group(5))
+        if kind == "conv":
+            return "conv_halo_x3_kernel", -(-M // 256) * (N // 128 if N % 128 == 0 else -(-N // 64)) * 512
+        if K >= 512 and N > 64:
+            return "gemm_x3_kernel<256", -(-M // 256) * -(-N // 128) * 512
+        return "gemm_x3_kernel<128", -(-M // 128) * -(-N // (128 if N > 64 else 64)) * 256
+    m = re.match(r"dual_(f16x3|bf16x3)_M(\d+)_N(\d+)_K(\d+)_K(\d+)$", name)
+    if m:
+        f16 = "true" if m.group(1) == "f16x3" else "false"
+        return f"gemm_x3_kernel<128, 2, false, {f16}, false, true>", -(-int(m.group(2)) // 128) * (int(m.group(3)) // 128) * 256
+    m = re.match(r"(tail|chain)_(f16x3|bf16x3)_c64_cn(\d+)(_ds)?_P(\d+)$", name)
+    if m:
+        f16 = "true" if m.group(2) == "f16x3" else "false"
+        return (f"chain_x3_kernel<{m.group(3)}, {f16}, {'true' if m.group(4) else 'false'}, {'true' if m.group(1) == 'tail' else 'false'}",
+                -(-int(m.group(5)) // 64) * 256)
+    m = re.match(r"chainw_(f16x3|bf16x3)_c(\d+)_cn(\d+)_P(\d+)$", name)
+    if m:
+        return f"chain_x3w_kernel<{m.group(2)}, {'true' if m.group(1) == 'f16x3' else 'false'}", -(-int(m.group(4)) // 128) * 512
+    if name in ("conv1_pool_f16x3", "conv1_pool_bf16x3"):
+        return "conv1_pool_x3_kernel", 256 * 512
+    return None
+
+
+def measure_traffic(roof, args, recs=()):
+    """HBM-side bytes per launch from the PMC counters of THIS build: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE cannot share a
+    pass: TCC slots) over one one-slide step of the same workload in child processes, corrected as MI355X_MICROARCH.md prescribes
+    (FETCH_SIZE counts 64 B per 128-byte request on gfx950: doubled; KiB units).  `roofline.traffic` = the dominant class;
+    `roofline.traffic_by_class` = every split-mode class whose launch geometry follows from its name (plain and dual products,
+    halo-staged 3x3, the 56x56 tails, the 28x28 / 14x14 chains, the stem) with its algorithmic bytes and the wasted-traffic ratio.
+    Runs by default for the default workload when rocprofv3 is on the box (--no-measure-traffic: the committed pass instead)."""
     import csv
     import glob
-    import re
     import shutil
     import subprocess
     import tempfile
-    m = re.match(r"(conv|gemm)_(f16x3|bf16x3)_M(\d+)_N(\d+)_K(\d+)$", roof.get("kernel", ""))
-    if not m or shutil.which("rocprofv3") is None:
+    if shutil.which("rocprofv3") is None:
         return False
-    kind, M, N, K = m.group(1), int(m.group(3)), int(m.group(4)), int(m.group(5))
-    if kind == "conv":
-        symbol, grid = "conv_halo_x3_kernel", -(-M // 256) * (N // 128 if N % 128 == 0 else -(-N // 64)) * 512
-    elif K >= 512 and N > 64:
-        symbol, grid = "gemm_x3_kernel<256", -(-M // 256) * -(-N // 128) * 512
-    else:
-        symbol, grid = "gemm_x3_kernel<128", -(-M // 128) * -(-N // (128 if N > 64 else 64)) * 256
-    got = {}
+    want = {}
+    for n in [r["name"] for r in recs] + [roof.get("kernel", "")]:
+        k = _kernel_of_class(n)
+        if k:
+            want[n] = k
+    if roof.get("kernel") not in want:
+        return False
+    alg = {r["name"]: r["bytes"] for r in recs}        # prof records carry bytes PER LAUNCH
+    alg.setdefault(roof["kernel"], roof.get("algorithmic_bytes", 0))
+    got = {c: {} for c in ("FETCH_SIZE", "WRITE_SIZE")}
     tmp = tempfile.mkdtemp(prefix="sq_pmc_", dir="/tmp")
+    t0 = time.time()
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.abspath(__file__), "--workload", args.workload, "--dtype", args.dtype, "--slides", "1", "--steps", "1", "--warmup", "1",
+                   os.path.abspath(__file__), "--workload", args.workload, "--dtype", args.dtype, "--slides", "1", "--steps", "1", "--warmup", "0",
                    "--patches", str(args.patches), "--patch-size", str(args.patch_size), "--sub-batch", str(args.sub_batch),
-                   "--no-secondary", "--no-cpu-baseline", "--no-accuracy"]
+                   "--no-secondary", "--no-cpu-baseline", "--no-accuracy", "--no-measure-traffic"]
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
-            vals = []
+            rows = []
             for f in glob.glob(out + "/**/*_counter_collection.csv", recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter and symbol in r["Kernel_Name"] and int(r["Grid_Size"]) == grid:
-                        vals.append(float(r["Counter_Value"]))
-            if not vals:
-                return False
-            got[counter] = sum(vals) / len(vals)
+                rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+            for name, (symbol, grid) in want.items():
+                vals = [float(r["Counter_Value"]) for r in rows if symbol in r["Kernel_Name"] and int(r["Grid_Size"]) == grid]
+                if vals:
+                    got[counter][name] = sum(vals) / len(vals)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    roof["traffic"] = round(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
+    by = {}
+    for name in want:
+        if name in got["FETCH_SIZE"] and name in got["WRITE_SIZE"]:
+            meas = got["FETCH_SIZE"][name] * 1024 * 2 + got["WRITE_SIZE"][name] * 1024
+            twins = sorted(n for n in want if n != name and want[n] == want[name])      # same symbol and grid: the counters cannot tell them apart
+            by[name] = {"hbm_bytes": round(meas), "algorithmic_bytes": round(alg.get(name, 0)),
+                        "ratio": round(meas / alg[name], 3) if alg.get(name) and not twins else None}
+            if twins:
+                by[name]["mean_over_launches_shared_with"] = twins
+    if roof["kernel"] not in by:
+        return False
+    roof["traffic"] = by[roof["kernel"]]["hbm_bytes"]
     roof["traffic_measured"] = True
-    roof["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes of this build, {symbol}... grid {grid}"
+    roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate one-slide passes of this build in child processes, "
+                              f"{round(time.time() - t0, 1)} s")
+    roof["traffic_by_class"] = by
     return True
 
 
@@ -728,6 +771,9 @@ def measure(name, args, rank, world, device, want_roofline=True, want_cpu=True):
     if LAST_POWER[0]:
         out["power"] = LAST_POWER[0]
         LAST_POWER[0] = None
+        if out["power"].get("package_w") and value > 0:
+            # the headline workload runs at the package power cap: joules per slide is what a change has to lower
+            out["power"]["energy_j_per_slide"] = round(out["power"]["package_w"] * world / value, 3)
     recs = []
     if want_roofline:
         roof, recs = roofline_from_profile(wl["step"], min(steps, 3), args.dtype, name)
@@ -790,7 +836,8 @@ def main():
     ap.add_argument("--resident", action="store_true", help="pipeline workload: patches already in HBM when the timed region starts "
                     "(default: uploaded from pinned host memory every step, as BASELINE config 3 states)")
     ap.add_argument("--measure-traffic", action="store_true", help="collect roofline.traffic with two rocprofv3 --pmc passes of this build "
-                    "(adds minutes; default: the figure of the committed pass under profiles/, traffic_measured false)")
+                    "(the default for the default workload when rocprofv3 is on the box)")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="keep the figure of the committed pass under profiles/ (traffic_measured false)")
     ap.add_argument("--no-accuracy", action="store_true", help="pipeline workload: skip the accuracy_vs_reference checker leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the secondary measurements")
@@ -840,9 +887,10 @@ def main():
             "host_numa_binding": numa, "power": res.get("power"),
             "ranks": torch.distributed.get_world_size() if world > 1 else 1,
             "backend": (torch.distributed.get_backend() if world > 1 else None)}
-    if args.measure_traffic and rank == 0 and world == 1 and line.get("roofline"):
+    default_wl = args.workload == "pipeline" and args.dtype == "f16x3" and args.embedder == "resnet"
+    if (args.measure_traffic or (default_wl and not args.no_measure_traffic)) and rank == 0 and world == 1 and line.get("roofline"):
         try:
-            measure_traffic(line["roofline"], args)
+            measure_traffic(line["roofline"], args, res.get("_recs") or ())
         except Exception as e:                          # a profiler problem must not cost the line
             line["roofline"]["traffic_error"] = f"{type(e).__name__}: {e}"
     if "check" in res:
@@ -868,7 +916,7 @@ def main():
                            ("train_kfold_64_slides_per_gpu", ["--workload", "train_kfold"]),      # BASELINE config 4's per-GPU share on this one GPU
                            ("pipeline_uni_vit_l16_embedder", ["--workload", "pipeline", "--embedder", "uni", "--slides", "2"]),
                            ("spatial_50k_tiles", ["--workload", "spatial"])):
-            cmd = [sys.executable, os.path.abspath(__file__), "--no-secondary", "--no-cpu-baseline", "--warmup", str(args.warmup)] + extra
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-secondary", "--no-cpu-baseline", "--no-measure-traffic", "--warmup", str(args.warmup)] + extra
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
                 last = [l for l in r.stdout.splitlines() if l.startswith("{")]
