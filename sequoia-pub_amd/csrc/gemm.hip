@@ -22,8 +22,6 @@
 #include <cstdio>
 #include <cstdlib>
 
-bool sq_gemm256_eligible(const GemmArgs& a, int dtype);
-int sq_launch_gemm256(const GemmArgs& a, hipStream_t stream);
 bool sq_conv_halo_eligible(const GemmArgs& a, int dtype);
 int sq_launch_conv_halo(const GemmArgs& a, hipStream_t stream);
 bool sq_gemm_w4_eligible(const GemmArgs& a, int dtype);
@@ -520,7 +518,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return SQ_OK;
 }
 
-int g_force_tile = 0, g_force_split = 0, g_use256 = -1, g_use_ring = -1;
+int g_force_tile = 0, g_force_split = 0, g_use_ring = -1;
 }
 int g_dbg = 0;                   // shared with gemm_x3.hip
 extern int g_tn_force_split, g_tn_ring;
@@ -569,10 +567,8 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
         if (g_use_ring < 0) { const char* e = getenv("SQ_GEMM_RING"); g_use_ring = (e && e[0] == '0') ? 0 : 1; }
         if (a.splitk == 1 && (g_force_tile == 33 || (g_force_tile == 0 && g_use_ring && sq_gemm_ring_eligible(a, SQ_BF16))) && a.N % 8 == 0)
             return sq_launch_gemm_ring(a, stream);
-        if (g_use256 < 0) g_use256 = sq_env_flag("SQ_GEMM256") ? 1 : 0;      // opt-in, see gemm256.hip
-        if ((g_force_tile == 44 || (g_force_tile == 0 && g_use256)) && a.splitk == 1 && sq_gemm256_eligible(a, SQ_BF16)) return sq_launch_gemm256(a, stream);
     }
-    if (tile == 22 || tile == 44) return launch_cfg<T, 2, 2>(a, stream);
+    if (tile == 22) return launch_cfg<T, 2, 2>(a, stream);
     if (tile == 21) return launch_cfg<T, 2, 1>(a, stream);
     if (tile == 12) return launch_cfg<T, 1, 2>(a, stream);
     return launch_cfg<T, 1, 1>(a, stream);
@@ -589,7 +585,6 @@ extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
     else if (key == 2) g_force_split = value;
-    else if (key == 5) g_use256 = value;
     else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
     else if (key == 15) g_tn_ring = value;            // gemm_tn.hip: ring form on / off (-1: environment)

@@ -186,33 +186,6 @@ def test_bad_arguments_fail_loudly():
     assert rc != 0 and b"misaligned" in lib.sq_last_error()
 
 
-@pytest.mark.parametrize("M,N,K", [(256 * 9 + 37, 512, 320), (700, 256 + 64, 1024)])
-def test_256_tile_variant_matches_default_tile(M, N, K):
-    """The opt-in 8-wave 256 x 256 tile (gemm256.hip), forced through the experiment knob: same products as the
-    default tile incl. ragged edges, bias, bf16 residual and ReLU."""
-    _lib.require_gpu()
-    lib = _lib.lib()
-    g = torch.Generator().manual_seed(M + N)
-    A = torch.randn(M, K, generator=g).cuda().bfloat16()
-    W = torch.randn(N, K, generator=g).cuda().bfloat16()
-    bias = torch.randn(N, generator=g).cuda()
-    res = torch.randn(M, N, generator=g).cuda().bfloat16()
-    outs = []
-    import os
-    os.environ["SQ_GEMM256_MIN_TILES"] = "1"
-    for tile in (22, 44):
-        lib.sq_dbg_set(0, tile)
-        C = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-        _lib.check(lib.sq_linear(_lib.SQ_BF16, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(bias), _lib.ptr(res), N, _lib.SQ_BF16, 2,
-                                 _lib.ptr(C), _lib.SQ_BF16, N, M, N, K, None, 0, _lib.stream_ptr()))
-        torch.cuda.synchronize()
-        outs.append(C.float())
-    lib.sq_dbg_set(0, 0)
-    ref = torch.relu(A.float() @ W.float().T + bias + res.float())
-    assert rel_err(outs[1].cpu(), ref.cpu()) < 1e-2
-    assert torch.equal(outs[0], outs[1])            # same K order and the same epilogue arithmetic -> same bits
-
-
 @pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("M,N,K,act", [(256 * 9 + 37, 512, 320, 2), (700, 256 + 64, 1024, 1), (3000, 768, 72, 0)])
 def test_four_stage_256_tile_variant_matches_default_tile(M, N, K, act, waves):

@@ -55,7 +55,7 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "big":
         for M, N, K in [(8192, 8192, 8192), (102400, 1024, 1024), (98000, 1024, 256), (98000, 512, 1024), (24500, 2048, 512), (392000, 512, 128), (98000, 256, 1024), (392000, 128, 512)]:
-            probe(M, N, K, _lib.SQ_BF16, tiles=(22, 44), dbgs=(0,))
+            probe(M, N, K, _lib.SQ_BF16, tiles=(22,), dbgs=(0,))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "w4t":
         # gemm_w4.hip with K-tile-major operand addressing (dbg 32: weights, 96: weights and activations), timing only
@@ -139,16 +139,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "w4":
         for M, N, K in [(8192, 8192, 8192), (4096, 4096, 4096), (102400, 1024, 1024), (50432, 4096, 1024), (50432, 1024, 4096), (24500, 512, 4608),
                         (24500, 2048, 1024), (98000, 1024, 512), (98000, 512, 1024), (6400, 1024, 1024)]:
-            probe(M, N, K, _lib.SQ_BF16, tiles=(0, 55, 33, 44), dbgs=(0,))
+            probe(M, N, K, _lib.SQ_BF16, tiles=(0, 55, 33), dbgs=(0,))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ring":
         for M, N, K in [(8192, 8192, 8192), (102400, 1024, 1024), (98000, 256, 2304), (98000, 256, 1024), (98000, 512, 1024),
                         (24500, 512, 4608), (24500, 2048, 1024), (392000, 128, 1152), (98000, 1024, 256), (6400, 1024, 1024)]:
-            probe(M, N, K, _lib.SQ_BF16, tiles=(22, 44, 33), dbgs=(0,))
+            probe(M, N, K, _lib.SQ_BF16, tiles=(22, 33), dbgs=(0,))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "uni":
         for M, N, K in [(50432, 4096, 1024), (50432, 1024, 4096), (50432, 3072, 1024), (50432, 1024, 1024), (102400, 2048, 2048)]:
-            probe(M, N, K, _lib.SQ_BF16, tiles=(22, 33, 44), dbgs=(0,))
+            probe(M, N, K, _lib.SQ_BF16, tiles=(22, 33), dbgs=(0,))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "l4":
         for M, N, K in [(24500, 512, 4608), (24500, 2048, 512), (24500, 512, 2048), (24500, 2048, 1024), (98000, 512, 1024), (6400, 1024, 1024)]:
