@@ -195,7 +195,7 @@ def roofline_from_profile(step_fn, steps, dtype_name, workload_name=""):
     # HBM-side bytes per launch of this kernel/shape from the committed rocprofv3 PMC passes of the same command
     # (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py)
     roof["traffic_measured"] = False          # read from the committed PMC passes of the same command, not from this run
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         pmc = os.path.join(ROOT, "profiles", f"{rnd}_{workload_name}_{dtype_name}_pmc.json")
         if os.path.exists(pmc):
             cls = json.load(open(pmc)).get("classes", {}).get(dom["name"])

@@ -31,6 +31,7 @@
 #include "x3_fmt.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 extern int g_dbg;                // sq_dbg_set key 1 (gemm.hip)
@@ -204,8 +205,13 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
             const uint16_t* row = p.t2 + (size_t)(ok ? pr : 0) * C + lh * 8;
 #pragma unroll
             for (int ks = 0; ks < Cfg::KS1; ++ks) {
-                xh[ks] = *reinterpret_cast<const u32x4*>(row + ks * 16);
-                xl[ks] = *reinterpret_cast<const u32x4*>(row + p.plT2 + ks * 16);
+                if (nt) {       // (read once: streaming policy like the identity tiles)
+                    xh[ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + ks * 16));
+                    xl[ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + p.plT2 + ks * 16));
+                } else {
+                    xh[ks] = *reinterpret_cast<const u32x4*>(row + ks * 16);
+                    xl[ks] = *reinterpret_cast<const u32x4*>(row + p.plT2 + ks * 16);
+                }
                 if (!ok) { xh[ks] = u32x4{0u, 0u, 0u, 0u}; xl[ks] = u32x4{0u, 0u, 0u, 0u}; }
             }
         }
@@ -435,8 +441,13 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
                     const int pr = p0 + row;
                     const uint32_t off = pr < p.P ? ((uint32_t)pr * N2 + (uint32_t)(cl * 8)) * 2u : OOB;
                     const u32x4 v = lds128(mine + e * 16);
-                    if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rsTh, off, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b128(v, rsTl, off, 0, 0);
+                    if (nt && (dbg & 256)) {      // (experiment: t1' with the streaming policy too)
+                        if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rsTh, off, 0, 2);
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, rsTl, off, 0, 2);
+                    } else {
+                        if (pl == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rsTh, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, rsTl, off, 0, 0);
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the plane's reads are done before the next plane overwrites the stage
@@ -482,6 +493,7 @@ int sq_launch_chain_x3w(int f16, int c, const uint16_t* t2, long long plT2, cons
     a.t2 = t2; a.plT2 = plT2; a.res = res; a.plRes = plRes; a.y = y; a.plY = plY; a.t1n = t1n; a.plT1n = plT1n;
     a.w3 = w3; a.w1n = w1n; a.plW = plW; a.b3 = b3; a.cs3 = cs3; a.b1n = b1n; a.cs1n = cs1n;
     a.P = (int)P; a.tiled = w_tiled; a.dbg = g_dbg;
+    { static int e = -1; if (e < 0) { const char* v = getenv("SQ_CHAINW_DBG"); e = v ? atoi(v) : 0; } a.dbg |= e; }
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
     a.w3_bytes = clamp(w3_bytes); a.w1n_bytes = clamp(w1n_bytes);
     a.tiles = (int)((P + 127) / 128);
