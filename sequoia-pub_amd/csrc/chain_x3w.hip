@@ -18,7 +18,7 @@
 //     retire in order: counted waits are exact;
 //   * wave B(pg): accumulates P2: t1'^T += w1'[:, slice] . y^T slice one slice behind, and issues EVERY store (y slices, t1')
 //     -- it never waits on vmcnt, so HBM write latency stalls nobody (a store in front of a counted wait makes the wait
-//     stricter: measured +1.3 us per slice in the one-role form of this kernel, profiles/r05_chainw_*).
+//     stricter: measured +1.3 us per slice in the one-role form of this kernel, profiles/r05_chainw_probe_one_role_form.txt).
 //   One s_barrier per step hands over y slices, ring slots and identity buffers; a step is one slice (C = 128) or half a
 //   slice (C = 256: P1 over half of K, P2 over one of its two k-steps), i.e. 24 + 24 MFMAs per SIMD pair either way.
 //   A's epilogue VALU work runs under B's MFMAs.
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
     constexpr int UNIT = Cfg::UNIT, UH = Cfg::UH, XYW = Cfg::XYW;
     const int dbg = DBG ? p.dbg : 0;              // the ablation switches exist in the DBG instantiation only
     // Streaming policy (nt) for the read-once identity tiles and the write-once y lines: keeps the re-read weights in L2.  Measured
-    // (tools/chainw_probe.py, profiles/r05_chainw_probe.txt): C = 256, whole-line stores: 856 -> 785 us; C = 128, whose y leaves in
+    // (tools/chainw_probe.py, profiles/r05_chainw_probe_roles_nt.txt): C = 256, whole-line stores: 856 -> 785 us; C = 128, whose y leaves in
     // half lines: 1093 -> 1282 us -- so only the 256-channel form uses it (dbg 64 flips the choice in the DBG instantiation)
     const bool nt = (C == 256) != ((dbg & 64) != 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
