@@ -51,13 +51,19 @@ __device__ __forceinline__ u32x4 lds128(const char* p) { return *reinterpret_cas
 __device__ __forceinline__ u32x2 lds64(const char* p) { return *reinterpret_cast<const u32x2*>(p); }
 __device__ __forceinline__ void st_lds64(char* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// n (wave-uniform) in {0, 4, 8, 12, 16}
+// n (wave-uniform, even, <= 16): waits until at most n vector-memory operations are outstanding
 __device__ __forceinline__ void wait_vm_n(int n) {
-    if (n >= 16) wait_vm<16>();
-    else if (n >= 12) wait_vm<12>();
-    else if (n >= 8) wait_vm<8>();
-    else if (n >= 4) wait_vm<4>();
-    else wait_vm<0>();
+    switch (n >> 1) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<2>(); break;
+        case 2: wait_vm<4>(); break;
+        case 3: wait_vm<6>(); break;
+        case 4: wait_vm<8>(); break;
+        case 5: wait_vm<10>(); break;
+        case 6: wait_vm<12>(); break;
+        case 7: wait_vm<14>(); break;
+        default: wait_vm<16>(); break;
+    }
 }
 
 struct ChainWArgs {
@@ -72,10 +78,13 @@ struct ChainWArgs {
     int dbg;                                     // ablation switches (tools/chainw_probe.py): 1 no global stores, 2 no identity reads, 4 no first product, 8 no second product, 16 no weight stream, 32 no epilogue, 64 flip the nt policy, 128 nothing (selects the DBG instantiation)
 };
 
-template <int C> struct ChainWCfg {
-    static constexpr int N2 = C, N1 = 4 * C, NS = N1 / 32, KS1 = C / 16, NT2 = N2 / 32;
-    static constexpr int H = C / 128;             // steps per slice
-    static constexpr int KSH = KS1 / H;           // k-steps of P1 per step (8)
+template <int C, int N2_> struct ChainWCfg {
+    static constexpr int N2 = N2_, N1 = 4 * C, NS = N1 / 32, KS1 = C / 16, NT2 = N2 / 32;
+    static constexpr int H = N2 / 128;            // steps per slice: the w1' part of a step is [N2 n][32 / H k] x 2 planes = 16 KiB
+    static constexpr int KSH = KS1 / H;           // k-steps of P1 per step (8; 4 for C = 128 with a 256-wide next reduce)
+    static constexpr int KTL = C / H / 32;        // k-tiles of the w3 part of a step
+    static constexpr int W3R = KTL / 2;           // block-wide LDS-DMA rounds per plane of the w3 part (A waves: 256 threads x 16 B)
+    static constexpr int NW3 = 2 * W3R;           // w3 pieces per A thread per step (the w1' part: 4)
     static constexpr int STEPS = H * NS + H;      // A works in steps [0, H NS), B in [H, H NS + H)
     static constexpr int T = 512, PX = 128;
     static constexpr int UNIT = 16384, UH = 8192; // ring unit: both planes / one plane
@@ -84,14 +93,14 @@ template <int C> struct ChainWCfg {
     static constexpr int XY = 4 * 3 * XYW;        // three slices per group: identity arriving, y being made, y being multiplied / stored
     static constexpr int BIAS_FLOATS = 2 * N1 + 2 * N2;        // b3 | cs3 | b1' | cs1'
     static constexpr int LDS_BYTES = RING + XY + BIAS_FLOATS * 4;
-    static_assert(C == 128 || C == 256, "C = 128 (28 x 28 stage) or 256 (14 x 14 stage)");
-    static_assert(32 * (C / H) * 4 == UNIT && N2 * (32 / H) * 4 == UNIT, "both unit kinds are 16 KiB");
+    static_assert((C == 128 && (N2 == 128 || N2 == 256)) || (C == 256 && N2 == 256), "C -> next width: 128 -> 128 | 256 (28 x 28 stage), 256 -> 256 (14 x 14 stage)");
+    static_assert(32 * (C / H) * 4 <= UNIT && N2 * (32 / H) * 4 == UNIT && KTL >= 2, "unit sizes");
     static_assert(32 * N2 * 2 * 4 <= RING, "t1' staging (one plane per pixel group) must fit the dead ring");
 };
 
-template <int C, bool F16, bool DBG>
+template <int C, int N2T, bool F16, bool DBG>
 __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
-    using Cfg = ChainWCfg<C>;
+    using Cfg = ChainWCfg<C, N2T>;
     using Fmt = X3Fmt<F16>;
     constexpr int N1 = Cfg::N1, N2 = Cfg::N2, NS = Cfg::NS, KSH = Cfg::KSH, NT2 = Cfg::NT2, H = Cfg::H, STEPS = Cfg::STEPS;
     constexpr int UNIT = Cfg::UNIT, UH = Cfg::UH, XYW = Cfg::XYW;
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
     // Streaming policy (nt) for the read-once identity tiles and the write-once y lines: keeps the re-read weights in L2.  Measured
     // (tools/chainw_probe.py, profiles/r05_chainw_probe_roles_nt.txt): C = 256, whole-line stores: 856 -> 785 us; C = 128, whose y leaves in
     // half lines: 1093 -> 1282 us -- so only the 256-channel form uses it (dbg 64 flips the choice in the DBG instantiation)
-    const bool nt = (C == 256) != ((dbg & 64) != 0);
+    const bool nt = (H == 2) != ((dbg & 64) != 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const RG = smem;
     char* const XYB = smem + Cfg::RING;
@@ -151,19 +160,21 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
         // (H = 1) or 32-byte (H = 2) rows).  unit_pieces(i): how many of them exist (per thread: one load each).
         auto unit_has3 = [&](int i) { return !(dbg & 16) && i < H * NS; };
         auto unit_has1 = [&](int i) { return !(dbg & 16) && i >= H && i < STEPS; };
+        constexpr int NW3 = Cfg::NW3, W3R = Cfg::W3R, KTL = Cfg::KTL, NPC = NW3 + 4;      // pieces per thread per step
         auto issue_piece = [&](int i, int r) {        // r compile-time after unrolling
             char* base = RG + (i % 3) * (2 * UNIT) + wave * 1024;
-            const int q = (r & 1) * 256 + ta;
-            if (r < 4) {
+            if (r < NW3) {
                 if (!unit_has3(i)) return;
                 const int s = i / H, h = i % H;
+                const int pl = r / W3R, q = (r % W3R) * 256 + ta;                 // (the plane of a round is a compile-time fact: guide T20)
                 const int row = q >> 2, cl = (q & 3) ^ ((row >> 2) & 3);
-                const int kt = h * 4 + (row >> 5), nn = s * 32 + (row & 31);
+                const int kt = h * KTL + (row >> 5), nn = s * 32 + (row & 31);
                 const uint32_t off = p.tiled ? (uint32_t)(((kt * N1 + nn) * 32 + cl * 8) * 2) : (uint32_t)((nn * C + kt * 32 + cl * 8) * 2);
-                if (r < 2) glds16(rsW3h, base + r * 4096, off); else glds16(rsW3l, base + r * 4096, off);     // (the plane of a round is a compile-time fact: guide T20)
+                if (pl == 0) glds16(rsW3h, base + (r % W3R) * 4096, off); else glds16(rsW3l, base + UH + (r % W3R) * 4096, off);
             } else {
                 if (!unit_has1(i)) return;
-                const int j = i - H, s = j / H, h = j % H, rr = r - 4;
+                const int j = i - H, s = j / H, h = j % H, rr = r - NW3;
+                const int q = (rr & 1) * 256 + ta;
                 uint32_t off;
                 if constexpr (H == 1) {
                     const int row = q >> 2, cl = (q & 3) ^ ((row >> 2) & 3);
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
         };
         auto issue_units = [&](int i) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) issue_piece(i, r);
+            for (int r = 0; r < NPC; ++r) issue_piece(i, r);
         };
         // identity of slice s -> this group's image s % 3: 4 loads per thread, piece r = (16-row half u = r >> 1, plane r & 1)
         auto identity_piece = [&](int s, int r) {
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
                 // (the identity goes out at the LAST step of a slice, behind the unit pieces: loads retire in order, and an HBM read in
                 // front of the L2-resident weight pieces would hold their count up)
                 const bool want_id = h == H - 1 && s + 1 < NS;
-                const int k = (unit_has3(i + 2) ? 4 : 0) + (unit_has1(i + 2) ? 4 : 0) + (want_id ? 4 : 0);
+                const int k = (unit_has3(i + 2) ? NW3 : 0) + (unit_has1(i + 2) ? 4 : 0) + (want_id ? 4 : 0);
                 if (s < NS && !(dbg & 4)) {
                     // ---- P1, K part h: y^T slice [32 ch][32 px] (+)= w3[32 s ..][K part] . t2^T
                     if (h == 0) {
@@ -249,8 +260,14 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
                         Fmt::mma(wh, xl[h * KSH + ks], accy);       // activation lo . weight hi
                         Fmt::mma(wl, xh[h * KSH + ks], accy);       // activation hi . weight lo
                         Fmt::mma(wh, xh[h * KSH + ks], accy);       // activation hi . weight hi
-                        if (ks < 4) { issue_piece(i + 2, 2 * ks); issue_piece(i + 2, 2 * ks + 1); }
-                        else if (want_id) identity_piece(s + 1, ks - 4);
+                        {   // this k-step's share of the step's requests: the unit pieces first, the identity pieces behind them
+                            constexpr int PPK = (NPC + 4 + KSH - 1) / KSH;
+#pragma unroll
+                            for (int j = ks * PPK; j < (ks + 1) * PPK; ++j) {
+                                if (j < NPC) issue_piece(i + 2, j);
+                                else if (j < NPC + 4 && want_id) identity_piece(s + 1, j - NPC);
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         wh = nh; wl = nl;
                     }
@@ -457,17 +474,17 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
     __syncthreads();                              // role A: matches role B's barrier in front of the t1' stage
 }
 
-template <int C, bool F16>
+template <int C, int N2, bool F16>
 int launch_chainw(const ChainWArgs& a, hipStream_t stream) {
-    using Cfg = ChainWCfg<C>;
+    using Cfg = ChainWCfg<C, N2>;
     static SqDevOnce attr;       // hipFuncSetAttribute is per device
     if (attr.needed()) {
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3w_kernel<C, F16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3w_kernel<C, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3w_kernel<C, N2, F16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        SQ_HIP_CHECK(hipFuncSetAttribute((const void*)chain_x3w_kernel<C, N2, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr.done();
     }
-    if (a.dbg) hipLaunchKernelGGL((chain_x3w_kernel<C, F16, true>), dim3(a.tiles), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL((chain_x3w_kernel<C, F16, false>), dim3(a.tiles), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
+    if (a.dbg) hipLaunchKernelGGL((chain_x3w_kernel<C, N2, F16, true>), dim3(a.tiles), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((chain_x3w_kernel<C, N2, F16, false>), dim3(a.tiles), dim3(Cfg::T), Cfg::LDS_BYTES, stream, a);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }
@@ -475,7 +492,7 @@ int launch_chainw(const ChainWArgs& a, hipStream_t stream) {
 }  // namespace
 
 // Which (C, next width) pairs the launch covers: the plain bottlenecks of layer 2 (128 -> 512 -> 128) and layer 3 (256 -> 1024 -> 256)
-bool sq_chain_x3w_eligible(int c, int n2) { return (c == 128 || c == 256) && n2 == c; }
+bool sq_chain_x3w_eligible(int c, int n2) { return (c == 128 && (n2 == 128 || n2 == 256)) || (c == 256 && n2 == 256); }
 
 // t2 [P, C], res / y [P, 4 C], t1n [P, n2] as hi / lo planes (pl* = elements between the planes);
 // w3 [4 C, C] and w1n [n2, 4 C] planes plW apart (row-major, or K-tile-major when w_tiled), biases / per-channel scales fp32 (scales may be null).
@@ -483,7 +500,7 @@ bool sq_chain_x3w_eligible(int c, int n2) { return (c == 128 || c == 256) && n2 
 int sq_launch_chain_x3w(int f16, int c, const uint16_t* t2, long long plT2, const uint16_t* res, long long plRes, uint16_t* y, long long plY,
                         uint16_t* t1n, long long plT1n, int n2, const uint16_t* w3, const uint16_t* w1n, long long plW, size_t w3_bytes, size_t w1n_bytes,
                         const float* b3, const float* cs3, const float* b1n, const float* cs1n, long long P, int w_tiled, hipStream_t stream) {
-    SQ_REQUIRE(sq_chain_x3w_eligible(c, n2), "chain_x3w: C=%d next width %d (128 -> 128 or 256 -> 256)", c, n2);
+    SQ_REQUIRE(sq_chain_x3w_eligible(c, n2), "chain_x3w: C=%d next width %d (128 -> 128 | 256, 256 -> 256)", c, n2);
     SQ_REQUIRE(P > 0 && P * 4 * c * 2 < (1ll << 31), "chain_x3w: %lld pixels exceed the 2 GiB descriptor limit", P);
     SQ_REQUIRE(t2 && res && y && t1n && w3 && w1n && b3 && b1n, "chain_x3w: null pointer");
     SQ_REQUIRE(w3_bytes >= (size_t)4 * c * c * 2 && w1n_bytes >= (size_t)n2 * 4 * c * 2, "chain_x3w: weight extents");
@@ -504,14 +521,15 @@ int sq_launch_chain_x3w(int f16, int c, const uint16_t* t2, long long plT2, cons
         prof = sq_prof_begin(name, 2.0 * P * (4.0 * c * c + 4.0 * c * n2), (double)P * 4.0 * (c + 4 * c + 4 * c + n2), stream);
     }
     int rc;
-    if (c == 256) rc = f16 ? launch_chainw<256, true>(a, stream) : launch_chainw<256, false>(a, stream);
-    else rc = f16 ? launch_chainw<128, true>(a, stream) : launch_chainw<128, false>(a, stream);
+    if (c == 256) rc = f16 ? launch_chainw<256, 256, true>(a, stream) : launch_chainw<256, 256, false>(a, stream);
+    else if (n2 == 256) rc = f16 ? launch_chainw<128, 256, true>(a, stream) : launch_chainw<128, 256, false>(a, stream);
+    else rc = f16 ? launch_chainw<128, 128, true>(a, stream) : launch_chainw<128, 128, false>(a, stream);
     if (prof >= 0) sq_prof_end(prof, stream);
     return rc;
 }
 
 // Probe / test entry (tests/test_gpu_x3.py, tools/chainw_probe.py): one launch on caller-provided planes (row-major or K-tile-major weights)
-extern "C" int sq_dbg_chain_x3w(int f16, int c, long long P, const void* t2_hi, const void* t2_lo, const void* res_hi, const void* res_lo,
+extern "C" int sq_dbg_chain_x3w(int f16, int c, int n2, long long P, const void* t2_hi, const void* t2_lo, const void* res_hi, const void* res_lo,
                                 void* y_hi, void* y_lo, void* t1n_hi, void* t1n_lo, const void* w3_hi, const void* w3_lo,
                                 const void* w1n_hi, const void* w1n_lo, const float* b3, const float* cs3, const float* b1n, const float* cs1n,
                                 int w_tiled, void* stream) {
@@ -520,7 +538,7 @@ extern "C" int sq_dbg_chain_x3w(int f16, int c, long long P, const void* t2_hi, 
     const uint16_t* w3 = (const uint16_t*)w3_hi; const uint16_t* w1 = (const uint16_t*)w1n_hi;
     const long long plW = (const uint16_t*)w3_lo - w3;
     SQ_REQUIRE((const uint16_t*)w1n_lo - w1 == plW, "dbg_chain_x3w: both weights must share the plane distance");
-    const size_t w3b = (size_t)4 * c * c * 2, w1b = (size_t)c * 4 * c * 2;
+    const size_t w3b = (size_t)4 * c * c * 2, w1b = (size_t)n2 * 4 * c * 2;
     return sq_launch_chain_x3w(f16, c, t2, (const uint16_t*)t2_lo - t2, res, (const uint16_t*)res_lo - res, y, (uint16_t*)y_lo - y, t1n, (uint16_t*)t1n_lo - t1n,
-                               c, w3, w1, plW, w3b, w1b, b3, cs3, b1n, cs1n, P, w_tiled, (hipStream_t)stream);
+                               n2, w3, w1, plW, w3b, w1b, b3, cs3, b1n, cs1n, P, w_tiled, (hipStream_t)stream);
 }

@@ -181,38 +181,39 @@ def _linear_x3_planes(fmt, A, W, cs, bias, res, M, N, K):
 
 
 @pytest.mark.parametrize("fmt", [1, 0])
-@pytest.mark.parametrize("C,P", [(256, 128), (256, 1000), (256, 3 * 196 + 5), (128, 256), (128, 1000), (128, 2 * 784 + 77)])
-def test_chain_x3w_is_bit_identical_to_the_two_launches(C, P, fmt):
+@pytest.mark.parametrize("C,N2,P", [(256, 256, 128), (256, 256, 1000), (256, 256, 3 * 196 + 5), (128, 128, 256), (128, 128, 1000), (128, 128, 2 * 784 + 77),
+                                    (128, 256, 128), (128, 256, 1000), (128, 256, 784 + 300)])
+def test_chain_x3w_is_bit_identical_to_the_two_launches(C, N2, P, fmt):
     """chain_x3w.hip (28 x 28 / 14 x 14 stages: expand 1x1 + identity + ReLU + the next block's reduce 1x1 in one launch, products
     transposed so that y stays in the wave that made it) against the two gemm_x3.hip launches it replaces, on the same planes:
     y and t1' must be equal bit for bit -- ragged last tiles, per-channel power-of-two weight scales, both plane formats."""
     _lib.require_gpu()
     lib = _lib.lib()
     vp = ctypes.c_void_p
-    lib.sq_dbg_chain_x3w.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong] + [vp] * 16 + [ctypes.c_int, vp]
-    g = torch.Generator().manual_seed(C * 13 + P + fmt)
+    lib.sq_dbg_chain_x3w.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong] + [vp] * 16 + [ctypes.c_int, vp]
+    g = torch.Generator().manual_seed(C * 13 + N2 + P + fmt)
     N1 = 4 * C
     t2 = torch.relu(torch.randn(P, C, generator=g)) * torch.rand(P, 1, generator=g) * 2
     res = torch.relu(torch.randn(P, N1, generator=g)) * 1.5
     w3 = torch.randn(N1, C, generator=g) * (1.0 / np.sqrt(C)) + torch.arange(N1)[:, None] * 1e-4
-    w1 = torch.randn(C, N1, generator=g) * (1.0 / np.sqrt(N1)) + torch.arange(C)[:, None] * 1e-4
+    w1 = torch.randn(N2, N1, generator=g) * (1.0 / np.sqrt(N1)) + torch.arange(N2)[:, None] * 1e-4
     s3 = 2.0 ** (torch.arange(N1) % 5 + 7).float() if fmt else torch.ones(N1)
-    s1 = 2.0 ** (torch.arange(C) % 3 + 9).float() if fmt else torch.ones(C)
-    b3, b1 = torch.randn(N1, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    s1 = 2.0 ** (torch.arange(N2) % 3 + 9).float() if fmt else torch.ones(N2)
+    b3, b1 = torch.randn(N1, generator=g).cuda(), torch.randn(N2, generator=g).cuda()
     cs3, cs1 = (1.0 / s3).cuda(), (1.0 / s1).cuda()
     T2, R = torch.stack(split(t2, fmt)).cuda(), torch.stack(split(res, fmt)).cuda()
     # both weights in ONE allocation per plane (the fused launch takes one plane distance for both)
     wall = torch.cat([(w3 * s3[:, None]).reshape(-1), (w1 * s1[:, None]).reshape(-1)])
     Wp = torch.stack(split(wall, fmt)).cuda().contiguous()
     W3 = Wp[:, :N1 * C].view(2, N1, C)
-    W1 = Wp[:, N1 * C:].view(2, C, N1)
+    W1 = Wp[:, N1 * C:].view(2, N2, N1)
     assert W3[1].data_ptr() - W3[0].data_ptr() == W1[1].data_ptr() - W1[0].data_ptr()
     W3c, W1c = W3.contiguous(), W1.contiguous()                 # (sq_linear_x3 wants each weight's planes in their own allocation)
     y_ref = _linear_x3_planes(fmt, T2, W3c, cs3, b3, R, P, N1, C)
-    t1_ref = _linear_x3_planes(fmt, y_ref, W1c, cs1, b1, None, P, C, N1)
+    t1_ref = _linear_x3_planes(fmt, y_ref, W1c, cs1, b1, None, P, N2, N1)
     y = torch.full((2, P, N1), float("nan"), device="cuda", dtype=PLANE[fmt])
-    t1 = torch.full((2, P, C), float("nan"), device="cuda", dtype=PLANE[fmt])
-    rc = lib.sq_dbg_chain_x3w(fmt, C, P, _lib.ptr(T2[0]), _lib.ptr(T2[1]), _lib.ptr(R[0]), _lib.ptr(R[1]), _lib.ptr(y[0]), _lib.ptr(y[1]),
+    t1 = torch.full((2, P, N2), float("nan"), device="cuda", dtype=PLANE[fmt])
+    rc = lib.sq_dbg_chain_x3w(fmt, C, N2, P, _lib.ptr(T2[0]), _lib.ptr(T2[1]), _lib.ptr(R[0]), _lib.ptr(R[1]), _lib.ptr(y[0]), _lib.ptr(y[1]),
                               _lib.ptr(t1[0]), _lib.ptr(t1[1]), _lib.ptr(W3[0]), _lib.ptr(W3[1]), _lib.ptr(W1[0]), _lib.ptr(W1[1]),
                               _lib.ptr(b3), _lib.ptr(cs3), _lib.ptr(b1), _lib.ptr(cs1), 0, _lib.stream_ptr())
     _lib.check(rc)
