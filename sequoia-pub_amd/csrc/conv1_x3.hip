@@ -32,7 +32,8 @@ constexpr int COUT_BYTES = MT * 32 * CROW;
 constexpr int LUT_BYTES = 2 * 3 * 256 * 2;
 constexpr int W_LD = 152;                // packed conv1 weight row: k = (ky*7 + kx)*3 + c, zero padded (resnet.hip)
 constexpr int NT = 512;
-constexpr int LDS_BYTES = 2 * IN_BYTES + COUT_BYTES + LUT_BYTES;
+constexpr int RW_BYTES = 16384;           // fragment-ordered weights of the fused reduce
+constexpr int LDS_BYTES = 2 * IN_BYTES + COUT_BYTES + LUT_BYTES + RW_BYTES;
 
 struct Conv1X3Args {
     const uint8_t* u8;          // [n, S, S, 3] or null
@@ -44,6 +45,12 @@ struct Conv1X3Args {
     uint16_t* out;              // hi plane [n, S/4, S/4, 64]; lo plane out_plane elements behind
     long long out_plane;
     int n, S, tiles_per_side, tiles;
+    // optional: the first bottleneck's reduce 1x1 (64 -> 64, src/resnet.py:75-77) on the pooled tile before it leaves the CU:
+    // t1 = relu(x . w1^T * cs1 + b1) as planes beside x -- the launch that would read x back (0.8 GB per 1000 patches) is gone
+    const uint16_t* w1;         // hi plane [64, 64] (row-major, or K-tile-major when w1_tiled); lo plane w_plane elements behind
+    int w1_tiled;
+    const float* b1; const float* cs1;
+    uint16_t* t1;               // hi plane [n, S/4, S/4, 64]; lo plane out_plane elements behind; null: not fused
 };
 
 template <bool F16>
@@ -92,6 +99,20 @@ __global__ __launch_bounds__(NT) void conv1_pool_x3_kernel(const Conv1X3Args p) 
     }
     const float bias = p.bias[wn * 32 + l31];
     const float cscale = p.colscale ? p.colscale[wn * 32 + l31] : 1.0f;
+    // fused reduce: waves 0-3 = (pixel half ri, channel half rj) of the 64 x 64 result; B fragments (both planes, 4 k-steps) in registers
+    const bool fuse = p.t1 != nullptr;
+    const int ri = (wave >> 1) & 1, rj = wave & 1;
+    // B fragments of the reduce in fragment order in LDS, written once per (persistent) block: [channel half rj][k-step][plane][lane][16 B]
+    // = 16 KiB (in registers -- 32 more beside the 112 of the conv weights -- the kernel spills)
+    char* const s_rw = smem + 2 * IN_BYTES + COUT_BYTES + LUT_BYTES;
+    if (fuse) {
+        for (int sl = tid; sl < 1024; sl += NT) {
+            const int ln = sl & 63, pl = (sl >> 6) & 1, ks = (sl >> 7) & 3, j = sl >> 9;
+            const int n = j * 32 + (ln & 31), k = ks * 16 + (ln >> 5) * 8;
+            const size_t o = p.w1_tiled ? ((size_t)(k >> 5) * 64 + n) * 32 + (k & 31) : (size_t)n * 64 + k;
+            *reinterpret_cast<u32x4*>(s_rw + sl * 16) = *reinterpret_cast<const u32x4*>(p.w1 + (pl ? p.w_plane : 0) + o);
+        }
+    }
     __syncthreads();                               // look-up table ready
 
     // A-fragment base addresses: conv pixel m = tile*32 + l31 -> (oy, ox) in the 17 x 17 tile
@@ -240,6 +261,61 @@ __global__ __launch_bounds__(NT) void conv1_pool_x3_kernel(const Conv1X3Args p) 
             uint16_t* dst = p.out + (((size_t)img * PH + TP * ty + py) * PH + TP * tx + px) * 64 + cg * 8;
             *reinterpret_cast<u32x4*>(dst) = hi;
             *reinterpret_cast<u32x4*>(dst + p.out_plane) = lo;
+            if (fuse) {     // the pooled tile as the A image of the reduce: [64 px][128 B] hi | lo over the (dead) input planes, chunk ^= (px >> 1) & 7
+                char* a = smem + pp * 128 + ((cg ^ ((pp >> 1) & 7)) << 4);
+                *reinterpret_cast<u32x4*>(a) = hi;
+                *reinterpret_cast<u32x4*>(a + 8192) = lo;
+            }
+        }
+        if (fuse) {
+            // ---- t1 = relu(x . w1^T * cs1 + b1): same K order, MFMA order and epilogue arithmetic as the gemm_x3.hip launch it replaces
+            __syncthreads();                       // the A image is complete; every thread has finished pooling (s_out is free)
+            if (wave < 4) {
+                f32x16 racc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+                const int row = ri * 32 + l31;
+                const char* arow = smem + row * 128;
+                const int sw = (row >> 1) & 7;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 ah = *reinterpret_cast<const u32x4*>(arow + (((2 * ks + g) ^ sw) << 4));
+                    const u32x4 al = *reinterpret_cast<const u32x4*>(arow + 8192 + (((2 * ks + g) ^ sw) << 4));
+                    const u32x4 bh = *reinterpret_cast<const u32x4*>(s_rw + (((rj * 4 + ks) * 2) * 64 + lane) * 16);
+                    const u32x4 bl = *reinterpret_cast<const u32x4*>(s_rw + (((rj * 4 + ks) * 2 + 1) * 64 + lane) * 16);
+                    F::mma(al, bh, racc);
+                    F::mma(ah, bl, racc);
+                    F::mma(ah, bh, racc);
+                }
+                char* dst = s_out + (ri * 32 + 4 * g) * CROW + (rj * 32 + l31) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(dst + ((r & 3) + 8 * (r >> 2)) * CROW) = racc[r];
+            }
+            __syncthreads();
+            {
+                const int pp = tid >> 3, cg = tid & 7;
+                const int py = pp >> 3, px = pp & 7;
+                const char* src = s_out + pp * CROW + cg * 32;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 16);
+                float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b1 + cg * 8), b1v = *reinterpret_cast<const f32x4*>(p.b1 + cg * 8 + 4);
+                float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+                if (p.cs1) {
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.cs1 + cg * 8), s1 = *reinterpret_cast<const f32x4*>(p.cs1 + cg * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; }
+                }
+                const float bb[8] = {b0[0], b0[1], b0[2], b0[3], b1v[0], b1v[1], b1v[2], b1v[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = x3_relu(sc[e] * v[e] + bb[e]);
+                u32x4 hi, lo;
+                x3_split8<F16>(v, hi, lo);
+                uint16_t* dst = p.t1 + (((size_t)img * PH + TP * ty + py) * PH + TP * tx + px) * 64 + cg * 8;
+                *reinterpret_cast<u32x4*>(dst) = hi;
+                *reinterpret_cast<u32x4*>(dst + p.out_plane) = lo;
+            }
+            // (the next tile's staging overwrites the A image: its readers are behind the barrier above; the next conv tile is written
+            // behind the next staging barrier, by which time every thread has read its t1 chunk of s_out)
         }
         // the next tile's staging only touches the input planes (all MFMA reads are behind the barrier above); its conv
         // tile is written after the next barrier, by which time every thread has finished pooling this one
@@ -250,11 +326,14 @@ __global__ __launch_bounds__(NT) void conv1_pool_x3_kernel(const Conv1X3Args p) 
 
 // out planes [n, S/4, S/4, 64] = split(maxpool(relu(colscale * conv1(normalise(patches)) + bias))); S a multiple of 32
 int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, const uint16_t* w152_hi, long long w_plane, const float* bias,
-                            const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream) {
+                            const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream,
+                            const uint16_t* w1_hi, int w1_tiled, const float* b1, const float* cs1, uint16_t* t1_hi) {
     SQ_REQUIRE(S % (4 * TP) == 0 && n >= 1, "conv1_pool_x3: patch size %d must be a multiple of %d", S, 4 * TP);
     Conv1X3Args a;
     a.u8 = u8; a.f32 = f32_nchw; a.w = w152_hi; a.w_plane = w_plane; a.bias = bias; a.colscale = colscale;
     a.out = out_hi; a.out_plane = out_plane; a.n = n; a.S = S;
+    SQ_REQUIRE(!t1_hi || (w1_hi && b1), "conv1_pool_x3: the fused reduce needs its weights and bias");
+    a.w1 = w1_hi; a.w1_tiled = w1_tiled; a.b1 = b1; a.cs1 = cs1; a.t1 = t1_hi;
     a.tiles_per_side = S / (4 * TP);
     const long long tiles = (long long)n * a.tiles_per_side * a.tiles_per_side;
     SQ_REQUIRE(tiles < (1ll << 31), "conv1_pool_x3: too many tiles");
@@ -269,8 +348,9 @@ int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, c
     int prof = -1;
     if (sq_prof_on()) {
         const double px_out = (double)n * (S / 2) * (S / 2);
-        prof = sq_prof_begin(f16 ? "conv1_pool_f16x3" : "conv1_pool_bf16x3", 2.0 * px_out * 64 * 147,
-                             (double)n * S * S * 3 + (double)n * (S / 4) * (S / 4) * 64 * 4, stream);
+        prof = sq_prof_begin(f16 ? (t1_hi ? "conv1_pool_reduce_f16x3" : "conv1_pool_f16x3") : (t1_hi ? "conv1_pool_reduce_bf16x3" : "conv1_pool_bf16x3"),
+                             2.0 * px_out * 64 * 147 + (t1_hi ? 2.0 * n * (S / 4) * (S / 4) * 64.0 * 64.0 : 0.0),
+                             (double)n * S * S * 3 + (double)n * (S / 4) * (S / 4) * 64 * 4 * (t1_hi ? 2 : 1), stream);
     }
     if (f16) hipLaunchKernelGGL(conv1_pool_x3_kernel<true>, dim3(grid), dim3(NT), LDS_BYTES, stream, a);
     else hipLaunchKernelGGL(conv1_pool_x3_kernel<false>, dim3(grid), dim3(NT), LDS_BYTES, stream, a);

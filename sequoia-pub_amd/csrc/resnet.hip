@@ -41,7 +41,8 @@ int sq_launch_chain_x3w(int f16, int c, const uint16_t* t2, long long plT2, cons
                         uint16_t* t1n, long long plT1n, int n2, const uint16_t* w3, const uint16_t* w1n, long long plW, size_t w3_bytes, size_t w1n_bytes,
                         const float* b3, const float* cs3, const float* b1n, const float* cs1n, long long P, int w_tiled, hipStream_t stream);
 int sq_launch_conv1_pool_x3(int f16, const uint8_t* u8, const float* f32_nchw, const uint16_t* w152_hi, long long w_plane, const float* bias,
-                            const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream);
+                            const float* colscale, uint16_t* out_hi, long long out_plane, int n, int S, hipStream_t stream,
+                            const uint16_t* w1_hi, int w1_tiled, const float* b1, const float* cs1, uint16_t* t1_hi);
 
 namespace {
 
@@ -319,13 +320,20 @@ extern "C" int sq_resnet50_extract_checked(int dtype, const void* weights, const
 
     const int OH1 = S / 2;
     int H = OH1 / 2;    // after the max-pool
+    bool stem_t1 = false;
     if (lp) {           // conv1 + bn1 + relu + maxpool in one kernel (conv1.hip)
         const sq_conv_desc& d = lay.conv[0];
         RUN(sq_launch_conv1_pool_bf16(patches_u8, patches_f32_nchw, (const bf16_t*)W(d), bias + d.b_off, (bf16_t*)b.act[1], n, S, st));
     } else if (x3) {    // the same fusion on hi / lo planes (conv1_x3.hip)
         const sq_conv_desc& d = lay.conv[0];
+        // the first bottleneck's reduce 1x1 (64 -> 64) rides in the stem launch (SQ_RESNET_NO_STEM_REDUCE=1: its own launch): its
+        // output lands in act[2], which the block loop below then finds as the first block's t1
+        const sq_conv_desc& r1 = lay.conv[1];
+        stem_t1 = r1.k == 1 && r1.stride == 1 && r1.cin == 64 && r1.cout == 64 && !sq_env_flag("SQ_RESNET_NO_STEM_REDUCE");
         RUN(sq_launch_conv1_pool_x3(f16, patches_u8, patches_f32_nchw, (const uint16_t*)W(d), lay.w_total, bias + d.b_off, colscale + d.b_off,
-                                    (uint16_t*)b.act[1], act_plane, n, S, st));
+                                    (uint16_t*)b.act[1], act_plane, n, S, st,
+                                    stem_t1 ? (const uint16_t*)W(r1) : nullptr, 1, stem_t1 ? bias + r1.b_off : nullptr,
+                                    stem_t1 ? colscale + r1.b_off : nullptr, stem_t1 ? (uint16_t*)b.act[2] : nullptr));
     } else {
         {   // conv1 + bn1 + relu
             const size_t work = (size_t)n * OH1 * OH1 * (CONV1_KP / 8);
@@ -354,7 +362,7 @@ extern "C" int sq_resnet50_extract_checked(int dtype, const void* weights, const
     const bool fuse56 = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && (128 + 2 * H + 2) * 128 <= 32768;
     const bool fuse_chain = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && !sq_env_flag("SQ_RESNET_NO_CHAIN");
     const bool fuse_chain256 = fuse_chain && !sq_env_flag("SQ_RESNET_NO_CHAIN256");
-    int xi = 1, ci = 1, t1i = -1;
+    int xi = 1, ci = 1, t1i = stem_t1 ? 2 : -1;
     const int blocks[4] = {3, 4, 6, 3};
     for (int li = 0; li < 4; ++li)
         for (int bk = 0; bk < blocks[li]; ++bk) {

@@ -278,15 +278,15 @@ def test_resnet50_x3_fused_chain_is_bit_identical(monkeypatch, mode):
     p = torch.from_numpy(synth.patches_u8(5, n_patches=3, size=224)).cuda()
     p256 = torch.from_numpy(synth.patches_u8(6, n_patches=1, size=256)).cuda()          # 64 x 64 maps (256-px patches): the WIDE tail form (208-row planes, three-stage ring, tap-major K like the implicit GEMM these maps take unfused)
     outs = {}
-    for tag, env in (("tail", {}), ("no_chainw", {"SQ_RESNET_NO_CHAINW": "1"}), ("chain", {"SQ_RESNET_NO_TAIL": "1"}), ("chain_no_ds", {"SQ_RESNET_NO_TAIL": "1", "SQ_RESNET_NO_CHAIN_DS": "1"}),
+    for tag, env in (("tail", {}), ("no_chainw", {"SQ_RESNET_NO_CHAINW": "1"}), ("no_stem_reduce", {"SQ_RESNET_NO_STEM_REDUCE": "1"}), ("chain", {"SQ_RESNET_NO_TAIL": "1"}), ("chain_no_ds", {"SQ_RESNET_NO_TAIL": "1", "SQ_RESNET_NO_CHAIN_DS": "1"}),
                      ("no_dual", {"SQ_RESNET_NO_DUAL": "1"}), ("dual_everywhere", {"SQ_RESNET_NO_CHAIN": "1"}),
-                     ("plain", {"SQ_RESNET_NO_CHAIN": "1", "SQ_RESNET_NO_DUAL": "1", "SQ_RESNET_NO_CHAINW": "1"})):
-        for k in ("SQ_RESNET_NO_TAIL", "SQ_RESNET_NO_CHAIN_DS", "SQ_RESNET_NO_CHAIN", "SQ_RESNET_NO_DUAL", "SQ_RESNET_NO_CHAINW"):
+                     ("plain", {"SQ_RESNET_NO_CHAIN": "1", "SQ_RESNET_NO_DUAL": "1", "SQ_RESNET_NO_CHAINW": "1", "SQ_RESNET_NO_STEM_REDUCE": "1"})):
+        for k in ("SQ_RESNET_NO_TAIL", "SQ_RESNET_NO_CHAIN_DS", "SQ_RESNET_NO_CHAIN", "SQ_RESNET_NO_DUAL", "SQ_RESNET_NO_CHAINW", "SQ_RESNET_NO_STEM_REDUCE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         outs[tag] = (m.extract_patches_u8(p), m.extract_patches_u8(p256))
     torch.cuda.synchronize()
     assert torch.isfinite(outs["tail"][0]).all()
-    for tag in ("tail", "no_chainw", "chain", "chain_no_ds", "no_dual", "dual_everywhere"):
+    for tag in ("tail", "no_chainw", "no_stem_reduce", "chain", "chain_no_ds", "no_dual", "dual_everywhere"):
         assert torch.equal(outs[tag][0], outs["plain"][0]) and torch.equal(outs[tag][1], outs["plain"][1]), tag
