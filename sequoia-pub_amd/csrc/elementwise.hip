@@ -328,6 +328,37 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const sq_transpose
     }
 }
 
+// the same for 2-byte elements with 4-byte accesses on both sides (the generic kernel moves 128 bytes per wave instruction): a lane
+// reads two neighbouring columns and writes two neighbouring rows.  Needs even lds / ldd / C and 4-byte aligned bases (the launcher
+// checks; else the generic kernel runs).
+__global__ __launch_bounds__(256) void transpose_multi_u16x2_kernel(const sq_transpose_jobs jobs) {
+    __shared__ uint16_t tile[64][66];
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].tile0) ++j;
+    const sq_transpose_job& J = jobs.job[j];
+    int t = blockIdx.x - J.tile0;
+    const int tc = (J.C + 63) / 64, tr = (J.ldd + 63) / 64;
+    const int z = t / (tc * tr);
+    t -= z * tc * tr;
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(J.src) + (long long)z * J.sstride;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(J.dst) + (long long)z * J.dstride;
+    const int c0 = (t % tc) * 64, r0 = (t / tc) * 64;
+    const int R = J.R, C = J.C, ldd = J.ldd, lds_ = J.lds;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 lanes x 2 elements per row, 8 rows per pass
+    for (int i = ty; i < 64; i += 8) {
+        const int r = r0 + i, c = c0 + 2 * tx;
+        uint32_t v = 0;
+        if (r < R && c < C) v = *reinterpret_cast<const uint32_t*>(src + (size_t)r * lds_ + c);      // C even: c + 1 < C too
+        tile[i][2 * tx] = (uint16_t)(v & 0xffffu);
+        tile[i][2 * tx + 1] = (uint16_t)(v >> 16);
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 8) {
+        const int c = c0 + i, r = r0 + 2 * tx;
+        if (r < ldd && c < C) *reinterpret_cast<uint32_t*>(dst + (size_t)c * ldd + r) = (uint32_t)tile[2 * tx][i] | ((uint32_t)tile[2 * tx + 1][i] << 16);
+    }
+}
+
 __global__ void cast_pad_kernel(const float* __restrict__ src, int lds_, void* __restrict__ dst, int out_bf16, int ldd, int R, int C) {
     const uint32_t total = (uint32_t)R * ldd;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -475,7 +506,14 @@ int sq_transpose_jobs_add(sq_transpose_jobs* jobs, const void* src, int lds_, vo
 
 int sq_k_transpose_multi(const sq_transpose_jobs& jobs, int elem_size, hipStream_t s) {
     if (jobs.n == 0) return SQ_OK;
-    if (elem_size == 2) hipLaunchKernelGGL(transpose_multi_kernel<uint16_t>, dim3(jobs.tiles), dim3(256), 0, s, jobs);
+    bool pairs = elem_size == 2;
+    for (int i = 0; i < jobs.n && pairs; ++i) {
+        const sq_transpose_job& J = jobs.job[i];
+        pairs = J.lds % 2 == 0 && J.ldd % 2 == 0 && J.C % 2 == 0 && ((uintptr_t)J.src & 3) == 0 && ((uintptr_t)J.dst & 3) == 0 &&
+                J.sstride % 2 == 0 && J.dstride % 2 == 0;
+    }
+    if (pairs) hipLaunchKernelGGL(transpose_multi_u16x2_kernel, dim3(jobs.tiles), dim3(256), 0, s, jobs);
+    else if (elem_size == 2) hipLaunchKernelGGL(transpose_multi_kernel<uint16_t>, dim3(jobs.tiles), dim3(256), 0, s, jobs);
     else if (elem_size == 4) hipLaunchKernelGGL(transpose_multi_kernel<uint32_t>, dim3(jobs.tiles), dim3(256), 0, s, jobs);
     else { sq_set_error("transpose_multi: elem_size %d", elem_size); return SQ_ERR_ARG; }
     SQ_LAUNCH_CHECK();
