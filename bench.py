@@ -229,8 +229,8 @@ def _kernel_of_class(name):
                 -(-int(m.group(5)) // 64) * 256)
     m = re.match(r"chainw_(f16x3|bf16x3)_c(\d+)_cn(\d+)_P(\d+)$", name)
     if m:
-        return f"chain_x3w_kernel<{m.group(2)}, {'true' if m.group(1) == 'f16x3' else 'false'}", -(-int(m.group(4)) // 128) * 512
-    if name in ("conv1_pool_f16x3", "conv1_pool_bf16x3"):
+        return f"chain_x3w_kernel<{m.group(2)}, {m.group(3)}, {'true' if m.group(1) == 'f16x3' else 'false'}", -(-int(m.group(4)) // 128) * 512
+    if name in ("conv1_pool_f16x3", "conv1_pool_bf16x3", "conv1_pool_reduce_f16x3", "conv1_pool_reduce_bf16x3"):
         return "conv1_pool_x3_kernel", 256 * 512
     return None
 

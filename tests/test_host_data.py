@@ -164,3 +164,20 @@ def test_numa_binding_helper_never_fails():
         os.environ.pop("SQ_NO_NUMA_BIND", None)
         os.sched_setaffinity(0, aff)
         torch.set_num_threads(nthr)
+
+
+def test_bench_kernel_class_geometry():
+    """bench.py maps a profiled kernel class to the (symbol, grid) rocprofv3 reports, for the per-class traffic table: the grids must
+    follow the launchers' tilings (chains: 128-pixel tiles of 512 threads; tails: 64-pixel tiles of 256; halo 3x3: 256 x 128 of 512)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sq_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    k = b._kernel_of_class
+    assert k("chainw_f16x3_c256_cn256_P196000") == ("chain_x3w_kernel<256, 256, true", 1532 * 512)
+    assert k("chainw_f16x3_c128_cn256_P784000") == ("chain_x3w_kernel<128, 256, true", 6125 * 512)
+    assert k("tail_f16x3_c64_cn64_ds_P3136000") == ("chain_x3_kernel<64, true, true, true", 49000 * 256)
+    assert k("conv_f16x3_M196000_N256_K2304") == ("conv_halo_x3_kernel", 766 * 2 * 512)
+    assert k("dual_f16x3_M196000_N1024_K256_K512")[1] == 1532 * 8 * 256
+    assert k("gemm_f16x3_M196000_N256_K1024") == ("gemm_x3_kernel<256", 766 * 2 * 512)
+    assert k("gemm_f32_M800_N2048_K2048_b1") is None

@@ -24,11 +24,12 @@ python tools/pmc_summary.py r05_pipeline_f16x3 gpurun_out/profiles_r05/r05_pipel
   "tail_f16x3_c64_cn64_P3136000=chain_x3_kernel<64, true, false, true>:12544000" \
   "tail_f16x3_c64_cn64_ds_P3136000=chain_x3_kernel<64, true, true, true>:12544000" \
   "tail_f16x3_c64_cn128_P3136000=chain_x3_kernel<128, true, false, true>:12544000" \
-  "chainw_f16x3_c256_cn256_P196000=chain_x3w_kernel<256, true, false>:784384" \
-  "chainw_f16x3_c128_cn128_P784000=chain_x3w_kernel<128, true, false>:3136000" \
+  "chainw_f16x3_c256_cn256_P196000=chain_x3w_kernel<256, 256, true, false>:784384" \
+  "chainw_f16x3_c128_cn128_P784000=chain_x3w_kernel<128, 128, true, false>:3136000" \
+  "chainw_f16x3_c128_cn256_P784000=chain_x3w_kernel<128, 256, true, false>:3136000" \
   "dual_f16x3_M784000_N512_K128_K256=gemm_x3_kernel<128, 2, false, true, false, true>:6272000" \
   "dual_f16x3_M196000_N1024_K256_K512=gemm_x3_kernel<128, 2, false, true, false, true>:3137536" \
-  "conv1_pool_f16x3=conv1_pool_x3_kernel<true>:131072"
+  "conv1_pool_reduce_f16x3=conv1_pool_x3_kernel<true>:131072"
 SQ_BENCH_KERNELS=gpurun_out/profiles_r05/r05_pipeline_f16x3_bench_kernels.json python bench.py --no-secondary --no-cpu-baseline --no-accuracy > gpurun_out/profiles_r05/r05_pipeline_f16x3_bench_line.json 2>/dev/null
 SQ_BENCH_KERNELS=gpurun_out/profiles_r05/r05_vis_train_bf16_bench_kernels.json python bench.py --workload vis_train --no-secondary --no-cpu-baseline > gpurun_out/profiles_r05/r05_vis_train_bf16_bench_line.json 2>/dev/null
 python bench.py > gpurun_out/profiles_r05/r05_bench_final.json 2> gpurun_out/profiles_r05/r05_bench_final.err
