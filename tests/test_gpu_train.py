@@ -359,3 +359,26 @@ def test_bf16_training_follows_the_fp32_oracle_for_twenty_steps():
           f"; worst relative gap {max(gaps):.2e} at step {int(np.argmax(gaps)) + 1}")
     assert ref[-1] < 0.9 * ref[0], "the reference itself must be learning on this batch"
     assert max(gaps) < 1e-2, gaps
+
+
+def test_adamw_per_bucket_is_bit_identical_to_one_pass(monkeypatch):
+    """SQ_ADAMW_BUCKETS=1 (opt-in: measured slower on one GPU): every bucket's AdamW update on the communication
+    stream as the backward pass completes it -- element-wise, so losses and parameters must equal the one-pass step bit for bit."""
+    _lib.require_gpu()
+    cfg = dict(num_outputs=500, input_dim=256, depth=3, nheads=4, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    x = torch.randn(8, 100, 256, generator=torch.Generator().manual_seed(11)).cuda()
+    y = (torch.rand(8, 500, generator=torch.Generator().manual_seed(12)) * 8).cuda()
+
+    def run():
+        torch.manual_seed(5)
+        m = ViS(**cfg, device="cuda:0", compute_dtype="bf16").to("cuda:0")
+        st = sq_train.FusedTrainStep(m, lr=1e-3)
+        losses = [float(st.step(x, y)[0]) for _ in range(4)]
+        torch.cuda.synchronize()
+        return losses, m.flat.detach().clone(), st
+
+    l0, p0, s0 = run()
+    monkeypatch.setenv("SQ_ADAMW_BUCKETS", "1")
+    l1, p1, s1 = run()
+    assert not s0.adamw_buckets and s1.adamw_buckets and s1.overlap
+    assert l0 == l1 and torch.equal(p0, p1)
