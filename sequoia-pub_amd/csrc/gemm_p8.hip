@@ -40,6 +40,11 @@
 // stays: the next tile's first wait is a counted vmcnt, and a counted wait cannot tell loads from stores -- on gfx950 they
 // retire OUT OF ORDER with respect to each other (tools/vmcnt_probe.hip: 90 % of the lanes see a sentinel when a wave
 // waits vmcnt(NS) for a load issued in front of NS stores), so it has to cover the stores too.
+// Round 5 (tools/gemm_probe.py p8e / p8d, profiles/r05_gemm_p8_probe_*): of the ~90 us the epilogues of 204800 x 1024 x 1024 (bf16
+// results) cost, 30 are read-out and arithmetic, 27 the issue of the stores (measured with every tile landing on tile (0, 0)) and
+// 30 their HBM traffic.  Keeping the packed rows of a tile's lower half in registers (32 VGPRs: 237 in all, no spills) and
+// storing one row group per K-tile under the NEXT tile's K loop was built, bit-equal -- and slower: 443 -> 459 us (50432 x 4096 x
+// 1024: 418 -> 417; K = 4096: 396 -> 401): the counted wait of every K-tile then has stores in front of it.  Removed.
 #include "gemm.h"
 #include "gemm_epi.h"
 
@@ -385,6 +390,14 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                     }
                 }
                 const u32x4 packed = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                if (DBG && (dbg & 64)) {                      // ablation: the whole epilogue but its global stores (tools/gemm_probe.py p8e)
+                    asm volatile("" ::"v"(packed), "v"(v[0]), "v"(v[7]));
+                    continue;
+                }
+                if (DBG && (dbg & 128)) {                     // ablation: every tile's results land on tile (0, 0): the stores without their HBM traffic
+                    *reinterpret_cast<u32x4*>(c16p + (long long)(m - m0_) * p.ldc + (e_n - n0_)) = packed;
+                    continue;
+                }
                 if (c32) {
                     float* d = c32 + (long long)m * p.ldc + e_n;
                     *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};

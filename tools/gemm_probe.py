@@ -136,6 +136,12 @@ if __name__ == "__main__":
         for M, N, K in [(8192, 8192, 8192), (50432, 4096, 1024)]:
             probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0, 1, 2, 4, 8, 6, 12, 10, 14, 0), scheds=(1,))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "p8e":
+        # what of the epilogue is the HBM write burst: 1 no epilogue read-out / math / stores, 64 everything but the global stores,
+        # 128 the stores of every tile onto tile (0, 0) (no HBM traffic); bf16 results
+        for M, N, K in [(50432, 4096, 1024), (204800, 1024, 1024)]:
+            probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(32, 1, 64, 128, 32, 1, 64, 128), scheds=(1,), out_bf16=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "w4":
         for M, N, K in [(8192, 8192, 8192), (4096, 4096, 4096), (102400, 1024, 1024), (50432, 4096, 1024), (50432, 1024, 4096), (24500, 512, 4608),
                         (24500, 2048, 1024), (98000, 1024, 512), (98000, 512, 1024), (6400, 1024, 1024)]:
