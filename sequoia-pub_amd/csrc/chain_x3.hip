@@ -93,6 +93,7 @@ struct ChainX3Args {
     uint32_t w2_bytes;
     int W, HW;                                   // map width and pixels per image (square maps)
     int dbg;                                     // ablation switches (tools/chain_probe.py): 1 no stores, 2 no identity reads, 4 no 3x3, 8 no second product
+    int xcd_walk;                                // tile walk (kernel comment)
     int nt;                                      // identity reads and y stores carry the streaming (nt) policy (SQ_X3_NT)
 };
 
@@ -126,7 +127,23 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             wbl[slot][s] = *reinterpret_cast<const u32x4*>(w1src + p.plW + (g * 4 + s) * 512);
         }
     };
-    const int p0 = blockIdx.x * PX;
+    // Tile walk of the tail form (p.xcd_walk; SQ_X3_TAIL_XCD_WALK = 0 plain order, 1 one contiguous run per XCD, n chunks of n tiles;
+    // default 64).  Workgroups go to the XCDs round-robin, so in the plain order the tiles that share the 3x3's 2 W + 2 halo rows run
+    // under eight different L2s and every halo row crosses the fabric again: 1.17 / 1.19 / 1.27 x the algorithmic bytes by the
+    // counters.  With chunks of 64 consecutive tiles per XCD (what its 32 CUs hold at a time) the re-reads are L2 hits: 1.007 / 1.02 /
+    // 1.03 x, 4.3 GB less per 1000 patches -- at the SAME rate (profiles/r05_tail_xcd_walk_ab.txt: the re-reads were served by the
+    // memory-side cache, never by DRAM; the launch is bound inside the CU).
+    int tile_id = blockIdx.x;
+    if (p.xcd_walk == 1) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        tile_id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    } else if (p.xcd_walk > 1) {
+        // chunked: XCD x takes chunks x, x + 8, ... of xcd_walk consecutive tiles (the chip as a whole still sweeps the tensor front to back)
+        const int c = p.xcd_walk, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int full = (int)(gridDim.x / (8 * c)) * (8 * c);          // tiles covered by whole rounds of eight chunks; the ragged rest keeps the plain order
+        if ((int)blockIdx.x < full) tile_id = ((i / c) * 8 + x) * c + i % c;
+    }
+    const int p0 = tile_id * PX;
     // ---- the launch's long-latency reads are requested before anything else and land while the 3x3 runs:
     // (a) the B fragments of the 64-deep products.  Wave w multiplies all 64 pixels by channels [64 w, 64 w + 64): no other
     //     wave reads those rows of w3 / wd, so they go straight from L2 into registers (lane (n = l31, half lh) of k-step ks
@@ -565,6 +582,7 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     a.xin = xin; a.plX = plX; a.wd = frag + FRAG_WD; a.bd = bd; a.csd = csd; a.wd_bytes = clamp(wd_bytes);
     a.t1 = t1; a.plT1 = plT1; a.w2 = frag + FRAG_W2; a.b2 = b2; a.cs2 = cs2; a.w2_bytes = (uint32_t)((FRAG - FRAG_W2) * 2); a.W = W; a.HW = HW; a.dbg = g_dbg;
     { static int env_nt = -2; if (env_nt == -2) { const char* e = getenv("SQ_X3_NT"); env_nt = e ? atoi(e) : -1; } a.nt = env_nt > 0 ? 1 : 0; }       // default off (no gain measured in the pipeline)
+    { static int env_walk = -1; if (env_walk < 0) { const char* e = getenv("SQ_X3_TAIL_XCD_WALK"); env_walk = e ? atoi(e) : 64; } a.xcd_walk = tail ? env_walk : 0; }
     using I64 = std::integral_constant<int, 64>; using I128 = std::integral_constant<int, 128>;
     using T = std::true_type; using F = std::false_type;
     auto pick_tail = [&](auto n2c, auto f16c, auto dsc) {
