@@ -239,8 +239,7 @@ int sq_launch_bottleneck_chain_c128(const bf16_t* t2, const bf16_t* res, bf16_t*
     SQ_REQUIRE(w3_bytes >= (size_t)C4 * C * 2 && w1n_bytes >= (size_t)cn * C4 * 2, "bottleneck chain: weight extents");
     ChainArgs a;
     a.t2 = t2; a.res = res; a.y = y; a.t1n = t1n; a.w3 = w3; a.w1n = w1n; a.b3 = b3; a.b1n = b1n;
-    static const int nw_env = getenv("SQ_CHAIN_NW") ? atoi(getenv("SQ_CHAIN_NW")) : 0;      // 4 or 8: experiment knob
-    const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (cn == 256 ? 8 : 4);               // measured: 304 vs 321 us / 249 vs 257 us
+    const int nw = cn == 256 ? 8 : 4;               // measured against the other count: 304 vs 321 us / 249 vs 257 us
     const int tp = 32 * nw;
     a.P = (int)P; a.tiles = (int)((P + tp - 1) / tp);
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };

@@ -94,7 +94,6 @@ struct ChainX3Args {
     int W, HW;                                   // map width and pixels per image (square maps)
     int dbg;                                     // ablation switches (tools/chain_probe.py): 1 no stores, 2 no identity reads, 4 no 3x3, 8 no second product
     int xcd_walk;                                // tile walk (kernel comment)
-    int nt;                                      // identity reads and y stores carry the streaming (nt) policy (SQ_X3_NT)
 };
 
 template <int N2, bool F16, bool DS, bool TAIL, bool WIDE = false>
@@ -166,8 +165,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
         const int m = min(p0 + u * 8 + rsub, p.P - 1);      // rows past P repeat the last one (never stored): no branch around the read
         const u32x4* qh = reinterpret_cast<const u32x4*>(p.res + (size_t)m * N1 + c8 * 8);
         const u32x4* ql = reinterpret_cast<const u32x4*>(p.res + p.plRes + (size_t)m * N1 + c8 * 8);
-        if (p.nt) { rh[u] = __builtin_nontemporal_load(qh); rl[u] = __builtin_nontemporal_load(ql); }
-        else { rh[u] = *qh; rl[u] = *ql; }
+        rh[u] = *qh; rl[u] = *ql;
     };
     constexpr int NEXTRA = 8;
     auto extra_reads = [&](int k) {                // group k of NEXTRA, 4 reads each
@@ -431,8 +429,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             if (m < p.P && !(p.dbg & 1)) {
                 u32x4* qh = reinterpret_cast<u32x4*>(p.y + (size_t)m * N1 + c8 * 8);
                 u32x4* ql = reinterpret_cast<u32x4*>(p.y + p.plY + (size_t)m * N1 + c8 * 8);
-                if (p.nt) { __builtin_nontemporal_store(hi, qh); __builtin_nontemporal_store(lo, ql); }
-                else { *qh = hi; *ql = lo; }
+                *qh = hi; *ql = lo;
             }
         }
     }
@@ -581,7 +578,6 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     a.w3_bytes = clamp(w3_bytes);
     a.xin = xin; a.plX = plX; a.wd = frag + FRAG_WD; a.bd = bd; a.csd = csd; a.wd_bytes = clamp(wd_bytes);
     a.t1 = t1; a.plT1 = plT1; a.w2 = frag + FRAG_W2; a.b2 = b2; a.cs2 = cs2; a.w2_bytes = (uint32_t)((FRAG - FRAG_W2) * 2); a.W = W; a.HW = HW; a.dbg = g_dbg;
-    { static int env_nt = -2; if (env_nt == -2) { const char* e = getenv("SQ_X3_NT"); env_nt = e ? atoi(e) : -1; } a.nt = env_nt > 0 ? 1 : 0; }       // default off (no gain measured in the pipeline)
     { static int env_walk = -1; if (env_walk < 0) { const char* e = getenv("SQ_X3_TAIL_XCD_WALK"); env_walk = e ? atoi(e) : 64; } a.xcd_walk = tail ? env_walk : 0; }
     using I64 = std::integral_constant<int, 64>; using I128 = std::integral_constant<int, 128>;
     using T = std::true_type; using F = std::false_type;

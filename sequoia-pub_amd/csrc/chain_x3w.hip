@@ -510,7 +510,6 @@ int sq_launch_chain_x3w(int f16, int c, const uint16_t* t2, long long plT2, cons
     a.t2 = t2; a.plT2 = plT2; a.res = res; a.plRes = plRes; a.y = y; a.plY = plY; a.t1n = t1n; a.plT1n = plT1n;
     a.w3 = w3; a.w1n = w1n; a.plW = plW; a.b3 = b3; a.cs3 = cs3; a.b1n = b1n; a.cs1n = cs1n;
     a.P = (int)P; a.tiled = w_tiled; a.dbg = g_dbg;
-    { static int e = -1; if (e < 0) { const char* v = getenv("SQ_CHAINW_DBG"); e = v ? atoi(v) : 0; } a.dbg |= e; }
     auto clamp = [](size_t b) { return (uint32_t)(b < 0x7fffffffu ? b : 0x7fffffffu); };
     a.w3_bytes = clamp(w3_bytes); a.w1n_bytes = clamp(w1n_bytes);
     a.tiles = (int)((P + 127) / 128);

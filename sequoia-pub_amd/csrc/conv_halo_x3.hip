@@ -408,10 +408,9 @@ int launch_halo(const GemmArgs& a, hipStream_t stream) {
         attr.done();
     }
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / Cfg::BN);
-    // all eight waves in step: the A/B switch, and the 64-column tile (12 MFMAs per step and wave: the load phase is the
-    // longer one and the ping-pong buys nothing -- 56 x 56 stage 478 vs 489 us)
-    static const bool lockstep_env = sq_env_flag("SQ_X3_LOCKSTEP");
-    const bool lockstep = lockstep_env || WTN == 1;
+    // all eight waves in step for the 64-column tile (12 MFMAs per step and wave: the load phase is the longer one and the
+    // ping-pong buys nothing -- 56 x 56 stage 478 vs 489 us)
+    const bool lockstep = WTN == 1;
     if (a.x3_f16 && lockstep) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, true, false>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
     else if (a.x3_f16) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, true, true>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);
     else if (lockstep) hipLaunchKernelGGL((conv_halo_x3_kernel<WTN, HROWS, false, false>), dim3(tiles), dim3(512), Cfg::LDS_BYTES, stream, a);

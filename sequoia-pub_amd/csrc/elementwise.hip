@@ -405,7 +405,7 @@ int sq_k_token_mean(const float* X, float* out, bf16_t* outh, int B, int N, int 
 int sq_k_token_mean_any(const void* X, int in_dtype, float* out, bf16_t* outh, int B, int N, int D, hipStream_t s) {
     SQ_REQUIRE(D % 4 == 0, "token_mean: D=%d must be a multiple of 4", D);
     const int total = B * (D / 4);
-    if (in_dtype == SQ_BF16 && D % 8 == 0 && (((uintptr_t)X | (uintptr_t)out | (uintptr_t)outh) & 15) == 0 && !sq_env_flag("SQ_ELEMENTWISE_NARROW"))
+    if (in_dtype == SQ_BF16 && D % 8 == 0 && (((uintptr_t)X | (uintptr_t)out | (uintptr_t)outh) & 15) == 0)
         hipLaunchKernelGGL(token_mean_bf16x8_kernel, dim3((B * (D / 8) + 63) / 64), dim3(256), 0, s, (const u32x4*)X, (float4*)out, (uint2*)outh, B, N, D / 8);
     else if (in_dtype == SQ_BF16)
         hipLaunchKernelGGL(token_mean_kernel<true>, dim3((total + 63) / 64), dim3(256), 0, s, X, (float4*)out, (uint2*)outh, B, N, D / 4);
@@ -425,8 +425,7 @@ int sq_k_ln_rows_any(const void* x, int in_dtype, const float* g, const float* b
     SQ_REQUIRE(D % 4 == 0 && D <= 4096 && D > 0, "ln_rows: D=%d must be a multiple of 4 and <= 4096", D);
     const dim3 grid((R + 3) / 4), block(256);
     const int ob = out_dtype == SQ_BF16;
-    const bool wide = in_dtype == SQ_BF16 && (D == 1024 || D == 2048) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)g | (uintptr_t)b) & 15) == 0 &&
-        !sq_env_flag("SQ_ELEMENTWISE_NARROW");
+    const bool wide = in_dtype == SQ_BF16 && (D == 1024 || D == 2048) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)g | (uintptr_t)b) & 15) == 0;
     if (wide) {
         if (D == 1024) hipLaunchKernelGGL((ln_rows_bf16x8_kernel<2>), grid, block, 0, s, (const u32x4*)x, g, b, y, ob, R, mean_out, rstd_out);
         else hipLaunchKernelGGL((ln_rows_bf16x8_kernel<4>), grid, block, 0, s, (const u32x4*)x, g, b, y, ob, R, mean_out, rstd_out);

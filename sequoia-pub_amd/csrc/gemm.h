@@ -62,9 +62,6 @@ struct GemmArgs {
     const float* bias2 = nullptr; const float* colscale2 = nullptr;
     int dH = 0, dW = 0, dOH = 0, dOW = 0, dstride = 1;
     int tile_group_m = 0;              // gemm_p8.hip: tile rows per group of the tile walk (set by its launcher)
-    int nt_stream = 0;                 // gemm_x3.hip: residual reads and plane stores carry the streaming (nt) policy (set by its launcher)
-    int nt_bf16 = 0;                   // gemm_p8.hip: bf16 results leave with non-temporal stores (set by its launcher)
-    int skew_cycles = 0;               // gemm_p8.hip, persistent form: start-up delay per skew step (set by its launcher)
     int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };
 

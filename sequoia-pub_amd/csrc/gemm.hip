@@ -518,7 +518,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return SQ_OK;
 }
 
-int g_force_tile = 0, g_force_split = 0, g_use_ring = -1;
+int g_force_tile = 0, g_force_split = 0, g_use_ring = 1;        // sq_dbg_set key 6 (tests / probes): 0 turns gemm_ring.hip off
 }
 int g_dbg = 0;                   // shared with gemm_x3.hip
 extern int g_tn_force_split, g_tn_ring;
@@ -557,14 +557,13 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
     if (g_force_split > 0 && a.splitk_ws && a.N % 8 == 0) a.splitk = g_force_split;
     if (g_force_tile >= 33 && g_force_split <= 0) a.splitk = 1;      // a forced special kernel (probes): its tile code is not a 64-multiple pair, the split heuristic above does not apply
     if constexpr (sizeof(T) == 2) {
-        // long-K products with enough 256 x 128 tiles: three-stage ring kernel (gemm_ring.hip); SQ_GEMM_RING=0 turns it off
+        // long-K products with enough 256 x 128 tiles: three-stage ring kernel (gemm_ring.hip); sq_dbg_set(6, 0) turns it off
         // 3x3 / stride-1 convolutions with enough 256 x 128 tiles: input tile resident in LDS (conv_halo.hip)
         if (g_force_tile == 0 && a.splitk == 1 && sq_conv_halo_eligible(a, SQ_BF16)) return sq_launch_conv_halo(a, stream);
         // large plain products: 256 x 256 x 64 tile, eight phases per pair of K-tiles (gemm_p8.hip); tile 88 forces it
         if (a.splitk == 1 && a.N % 8 == 0 && !a.conv && (g_force_tile == 88 || (g_force_tile == 0 && sq_gemm_p8_eligible(a, SQ_BF16)))) return sq_launch_gemm_p8(a, stream);
         // large products: 256 x 256 tile on four waves, 128 x 128 per wave (gemm_w4.hip); tile 55 forces it
         if (a.splitk == 1 && a.N % 8 == 0 && (g_force_tile == 55 || (g_force_tile == 0 && sq_gemm_w4_eligible(a, SQ_BF16)))) return sq_launch_gemm_w4(a, stream);
-        if (g_use_ring < 0) { const char* e = getenv("SQ_GEMM_RING"); g_use_ring = (e && e[0] == '0') ? 0 : 1; }
         if (a.splitk == 1 && (g_force_tile == 33 || (g_force_tile == 0 && g_use_ring && sq_gemm_ring_eligible(a, SQ_BF16))) && a.N % 8 == 0)
             return sq_launch_gemm_ring(a, stream);
     }
@@ -580,18 +579,17 @@ int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return laun
 
 int g_x3_small_max_k = -1, g_x3_halo = -1;
 extern int g_w4_waves;
-extern int g_p8_sched, g_p8_group_m, g_p8_skew, g_p8_bn, g_p8_on;
+extern int g_p8_sched, g_p8_group_m, g_p8_bn, g_p8_on;
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
     else if (key == 1) g_dbg = value;
     else if (key == 2) g_force_split = value;
     else if (key == 6) g_use_ring = value;
     else if (key == 4) g_tn_force_split = value;
-    else if (key == 15) g_tn_ring = value;            // gemm_tn.hip: ring form on / off (-1: environment)
+    else if (key == 15) g_tn_ring = value;            // gemm_tn.hip: ring form on / off
     else if (key == 7) g_x3_small_max_k = value;
     else if (key == 14) g_p8_on = value;             // gemm_p8.hip on / off (-1: environment)
     else if (key == 13) g_p8_bn = value;             // gemm_p8.hip: forced tile width (128 / 256)
-    else if (key == 12) g_p8_skew = value;           // gemm_p8.hip, persistent form: start-up skew in cycles per step
     else if (key == 11) g_p8_group_m = value;        // gemm_p8.hip: tile rows per group of the tile walk
     else if (key == 10) g_p8_sched = value;          // gemm_p8.hip: schedule variant
     else if (key == 9) g_w4_waves = value;           // gemm_w4.hip: 4 or 8 waves per 256 x 256 tile

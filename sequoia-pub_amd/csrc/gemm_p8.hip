@@ -119,17 +119,6 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
     int idx = blockIdx.x >> 3;
     if (idx >= run_count(xcd)) return;
     const int t_cur = run_start(xcd) + idx;
-    if constexpr (PERSIST) {
-        // experiment knob (tools/gemm_probe.py p8p): a start-up delay of (i mod 4) steps, to let the stores of some CUs run under
-        // the K loops of others -- does not pay (launcher comment)
-        if (p.skew_cycles != 0) {
-            const long long t0 = __builtin_readcyclecounter();
-            // skew > 0: by block within the XCD (i mod 4 steps); skew < 0: by XCD parity (odd XCDs start |skew| cycles late: the blocks of an
-            // XCD stay in step and keep sharing operand panels in L2, the store bursts of the two halves of the chip alternate)
-            const long long wait = p.skew_cycles > 0 ? (long long)(idx & 3) * p.skew_cycles : (long long)(xcd & 1) * -(long long)p.skew_cycles;
-            while ((long long)__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     tile_coords(t_cur, m0, n0);
 
     const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.sA;
@@ -403,14 +392,9 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                     *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 }
-                // non-temporal stores for bf16 results (SQ_GEMM_P8_NT=1): -5.5 % on 50432 x 4096 x 1024, -6 % on 102400 x 1024 x 1024 and -3 % on
-                // 8192^3 in the probe (tools/gemm_probe.py p8nt; fp32 results: level or slower) -- and NOTHING in the applications (UNI 6.81 vs
-                // 6.79 slides/s, spatial 447 vs 450 ms): there the next kernel re-reads the tensor, part of it from the caches the
-                // non-temporal store bypassed.  Off by default.
-                if (c16p) {
-                    if (!p.nt_bf16 || (DBG && (dbg & 32))) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = packed;
-                    else __builtin_nontemporal_store(packed, reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n));
-                }
+                // (non-temporal stores for bf16 results: -3 ... -6 % in the probe, nothing in the applications -- the next kernel re-reads the
+                // tensor, part of it from the caches such a store bypasses; removed in round 5)
+                if (c16p) *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) = packed;
                 if (p.C2) *reinterpret_cast<u32x4*>(p.C2 + (long long)z * p.sC2 + (long long)m * p.ldc2 + e_n) = packed;   // bf16 operand copy
             }
         };
@@ -470,20 +454,18 @@ int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
     if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.rowbias || !a.vec_epi) return 0;
     if (a.ln64_g && (a.N % 64 || !a.ln64_b)) return 0;
     if (a.ln64_g && a.gelu_grad_of) return 0;          // no epilogue of this kernel does both (LayerNorm(64) is forward, GELU' backward)
-    static int on = -1, min_tiles = 0, min_k = 0, on128 = 0;
+    static int on = -1, min_tiles = 0;
+    constexpr int min_k = 512;
     if (on < 0) {
         const char* e = getenv("SQ_GEMM_P8");
         on = (e && e[0] == '0') ? 0 : 1;          // SQ_GEMM_P8=0: back to gemm_w4.hip (the A/B of tools/gemm_probe.py p8)
         const char* mt = getenv("SQ_GEMM_P8_MIN_TILES");
         min_tiles = mt ? atoi(mt) : 176;            // tools/gemm_probe.py p8m: ahead of the kernels it replaces from 192 tiles (24500 x 512 x 2048: 932 vs 837 TF), level at 200 x K 1024, behind at 100
-        const char* mk = getenv("SQ_GEMM_P8_MIN_K");
-        min_k = mk ? atoi(mk) : 512;
-        // the 256 x 128 shape is opt-in: on the ViS training step's 6400 x 1024 x 1024 products it equals the 128 x 128 kernel in
-        // isolation (23.1 vs 23.0 us; its phases hold 8 MFMAs, too few to amortise two barriers) and loses in the step (3.80 vs 3.55 ms):
-        // a block that owns a whole CU leaves no room for the weight-gradient products of the helper stream
-        const char* e1 = getenv("SQ_GEMM_P8_BN128");
-        on128 = (e1 && e1[0] == '1') ? 1 : 0;
     }
+    // The 256 x 128 shape is reached through sq_dbg_set key 13 only (tests, probes): on the ViS training step's 6400 x 1024 x 1024
+    // products it equals the 128 x 128 kernel in isolation (23.1 vs 23.0 us; its phases hold 8 MFMAs, too few to amortise two barriers)
+    // and loses in the step (3.80 vs 3.55 ms): a block that owns a whole CU leaves no room for the weight-gradient products of the helper stream.
+    constexpr int on128 = 0;
     if (!(g_p8_on >= 0 ? g_p8_on : on) || a.K % 8 || a.K < min_k) return 0;
     const long long rows = (a.M + BM - 1) / BM;
     // the GELU' epilogue (backward pass) reads a second [M, N] operand per tile: with fewer than two full rounds of tiles the
@@ -496,9 +478,8 @@ int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
 }
 bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype) { return sq_gemm_p8_shape(a, dtype) != 0; }
 
-int g_p8_group_m = -1;             // sq_dbg_set key 11: tile rows per group of the tile walk (-1 = environment SQ_GEMM_P8_GROUP_M or 8)
-int g_p8_sched = -1;               // sq_dbg_set key 10 (probes): 0 = one block per tile, 1 = persistent blocks; -1 = environment (SQ_GEMM_P8_PERSIST) or 1
-int g_p8_skew = -1;                // sq_dbg_set key 12: start-up skew of the persistent form in cycles per step (-1 = environment SQ_GEMM_P8_SKEW or none)
+int g_p8_group_m = -1;             // sq_dbg_set key 11: tile rows per group of the tile walk (-1 = 8)
+int g_p8_sched = -1;               // sq_dbg_set key 10 (probes): 0 = one block per tile, 1 = persistent blocks; -1 = persistent
 int g_p8_bn = -1;                  // sq_dbg_set key 13: forced tile width (128 / 256) when the kernel is forced (tile 88); -1 = by shape
 namespace {
 template <int EPI, bool PERSIST, bool DBG, int BNT>
@@ -538,14 +519,8 @@ int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
     SQ_REQUIRE(!a.rowbias, "gemm_p8: no row-bias epilogue");
     SQ_REQUIRE(!(a.ln64_g && a.gelu_grad_of), "gemm_p8: LayerNorm(64) and GELU' epilogues cannot be combined");
     SQ_REQUIRE(a.K % 8 == 0, "gemm_p8: K=%d must be a multiple of 8 (16-byte operand chunks), also when the tile is forced", a.K);
-    static int env_gm = -1, env_persist = -1, env_skew = -2;
-    if (env_gm < 0) { const char* e = getenv("SQ_GEMM_P8_GROUP_M"); env_gm = e ? atoi(e) : 8; }
-    if (env_persist < 0) { const char* e = getenv("SQ_GEMM_P8_PERSIST"); env_persist = e ? atoi(e) : 1; }
-    if (env_skew == -2) { const char* e = getenv("SQ_GEMM_P8_SKEW"); env_skew = e ? atoi(e) : -1; }
+    constexpr int env_gm = 8, env_persist = 1;
     a.tile_group_m = g_p8_group_m > 0 ? g_p8_group_m : env_gm;
-    static int env_nt = -1;
-    if (env_nt < 0) { const char* e = getenv("SQ_GEMM_P8_NT"); env_nt = (e && e[0] == '1') ? 1 : 0; }          // opt-in: see the epilogue
-    a.nt_bf16 = env_nt;
     int bn = sq_gemm_p8_shape(a, SQ_BF16);
     if (g_p8_bn == 128 || g_p8_bn == 256) bn = g_p8_bn;         // probes / tests
     if (bn == 0) bn = 256;                                        // forced (tile 88) on a shape the heuristics would not pick
@@ -553,9 +528,8 @@ int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
     const bool persist = (g_p8_sched >= 0 ? g_p8_sched : env_persist) != 0 && a.batch == 1;
     const int cus = p8_cus() & ~7;
     if (persist && tiles > cus && cus >= 8) {
-        // start-up skew (experiment knob, default none): measured SLOWER by more than the delay itself (50432 x 4096 x 1024: 454 us
-        // in step, 527 us with a quarter-tile skew) -- blocks of an XCD that drift apart stop sharing operand panels in L2
-        a.skew_cycles = g_p8_skew != -1 ? g_p8_skew : env_skew != -1 ? env_skew : 0;       // -1 = unset; other negatives: skew by XCD parity
+        // (a start-up skew between the blocks of an XCD, or between the XCDs, to spread the store bursts: slower by more than the delay /
+        // within noise -- blocks that drift apart stop sharing operand panels in L2; removed in round 5)
         return bn == 256 ? launch_p8_pick<true, 256>(a, dim3(cus, 1, 1), stream) : launch_p8_pick<true, 128>(a, dim3(cus, 1, 1), stream);
     }
     return bn == 256 ? launch_p8_pick<false, 256>(a, dim3(tiles, 1, a.batch), stream) : launch_p8_pick<false, 128>(a, dim3(tiles, 1, a.batch), stream);

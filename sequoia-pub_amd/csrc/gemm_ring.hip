@@ -297,13 +297,7 @@ bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype) {
     // only the epilogues the prefetching fast path covers (bias, residual, ReLU / GELU, a second bf16 copy): with one
     // block per CU nothing hides a generic epilogue -- row-bias / pre-activation-copy products measured 2x slower here
     if (a.rowbias || a.Cpre || a.gelu_grad_of) return false;
-    static int min_tiles = -1, min_k = -1;
-    if (min_tiles < 0) {
-        const char* e = getenv("SQ_GEMM_RING_MIN_TILES");
-        min_tiles = e ? atoi(e) : 448;
-        const char* k = getenv("SQ_GEMM_RING_MIN_K");
-        min_k = k ? atoi(k) : 512;
-    }
+    constexpr int min_tiles = 448, min_k = 512;
     const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.batch;
     // strided 1x1 convolutions (the downsample branches) gain from the 256-row tile already at K = 256: the layer-2 one
     // 315 -> 265 us; plain K = 256 products with a residual epilogue lose (143 -> 182 us) and stay on gemm.hip

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const GemmArgs p, con
 
 int g_tn_force_split = 0;      // experiment knob (sq_dbg_set key 4)
 extern int g_dbg;               // sq_dbg_set key 1 (gemm.hip)
-int g_tn_ring = -1;            // sq_dbg_set key 15 (tests / probes): 0 / 1 overrides SQ_GEMM_TN_RING
+int g_tn_ring = 1;             // sq_dbg_set key 15 (tests / probes): 0 turns the ring form off
 
 int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
     GemmArgs a = a_in;
@@ -606,8 +606,7 @@ int sq_launch_gemm_tn(const GemmArgs& a_in, int dtype, hipStream_t stream) {
     const int nk = (a.K + kr - 1) / kr;
     const long long tiles = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     a.splitk = 1;
-    // large bf16 gradients: the four-stage ring form (one 8-wave block per CU); SQ_GEMM_TN_RING=0 / sq_dbg_set(15, 0) turns it off
-    if (g_tn_ring < 0) { const char* e = getenv("SQ_GEMM_TN_RING"); g_tn_ring = (e && e[0] == '0') ? 0 : 1; }
+    // large bf16 gradients: the four-stage ring form (one 8-wave block per CU); sq_dbg_set(15, 0) turns it off
     if (g_tn_ring && dtype == SQ_BF16 && a.M % 128 == 0 && a.N % 128 == 0 && (a.batch == 1 || a.ngroup) && nk >= 8 &&
         tiles * a.batch >= 8) {
         const long long work = tiles * a.batch;

@@ -312,22 +312,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_w4_kernel(const GemmArgs p) {
 // prefetching fast path covers
 bool sq_gemm_w4_eligible(const GemmArgs& a, int dtype) {
     if (dtype != SQ_BF16 || a.splitk != 1 || a.ln64_g || a.rowbias || a.Cpre || a.gelu_grad_of || !a.vec_epi) return false;
-    static int on = -1, min_tiles = 0, min_k = 0;
-    if (on < 0) {
-        const char* e = getenv("SQ_GEMM_W4");
-        on = (e && e[0] == '0') ? 0 : 1;
-        const char* mt = getenv("SQ_GEMM_W4_MIN_TILES");
-        min_tiles = mt ? atoi(mt) : 232;
-        const char* mk = getenv("SQ_GEMM_W4_MIN_K");
-        min_k = mk ? atoi(mk) : 512;
-    }
-    if (!on) return false;
+    constexpr int min_tiles = 232, min_k = 512;
     if (a.conv && a.Cin % BK) return false;
     const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.batch;
     return a.K % 8 == 0 && a.K >= min_k && a.N % BN == 0 && tiles >= min_tiles;
 }
 
-int g_w4_waves = -1;              // sq_dbg_set key 9 (tests / probes): 4 or 8 waves, -1 = environment (SQ_GEMM_W4_WAVES) or 8
+int g_w4_waves = -1;              // sq_dbg_set key 9 (tests / probes): 4 = the one-wave-per-SIMD form, otherwise eight waves
 namespace {
 template <int EPI, int NW>
 int launch_w4(const GemmArgs& a, dim3 grid, hipStream_t stream) {
@@ -347,8 +338,6 @@ int launch_w4(const GemmArgs& a, dim3 grid, hipStream_t stream) {
 int sq_launch_gemm_w4(const GemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles, 1, a.batch);
-    static int env_waves = -1;
-    if (env_waves < 0) { const char* e = getenv("SQ_GEMM_W4_WAVES"); env_waves = (e && atoi(e) == 4) ? 4 : 8; }
-    if ((g_w4_waves > 0 ? g_w4_waves : env_waves) == 4) return a.act == SQ_ACT_GELU ? launch_w4<1, 4>(a, grid, stream) : launch_w4<0, 4>(a, grid, stream);
+    if (g_w4_waves == 4) return a.act == SQ_ACT_GELU ? launch_w4<1, 4>(a, grid, stream) : launch_w4<0, 4>(a, grid, stream);
     return a.act == SQ_ACT_GELU ? launch_w4<1, 8>(a, grid, stream) : launch_w4<0, 8>(a, grid, stream);
 }

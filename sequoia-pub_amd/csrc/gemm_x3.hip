@@ -37,16 +37,11 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_ba
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_base, 16, voffset, soffset, 0, 0);
 }
 __device__ __forceinline__ u32x4 lds_read128(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
-// 16-byte global accesses with an optional streaming (nt) policy: activations that are written once and read once by the next
-// launch are far larger than any cache; marked streaming they stop evicting the weight tiles every block re-reads from L2
-__device__ __forceinline__ u32x4 ld16(const bf16_t* p, bool nt) {
-    const u32x4* q = reinterpret_cast<const u32x4*>(p);
-    return nt ? __builtin_nontemporal_load(q) : *q;
-}
-__device__ __forceinline__ void st16(bf16_t* p, const u32x4& v, bool nt) {
-    u32x4* q = reinterpret_cast<u32x4*>(p);
-    if (nt) __builtin_nontemporal_store(v, q); else *q = v;
-}
+// 16-byte global accesses.  (A streaming (nt) policy on the residual reads and plane stores -- activations written once and read once
+// by the next launch -- was an experiment switch until round 5: pipeline 34.1 / 34.4 slides/s without, 34.1 / 34.1 with; only
+// chain_x3w.hip's 256-channel form gains from it and carries it unconditionally.)
+__device__ __forceinline__ u32x4 ld16(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(bf16_t* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 constexpr int BK = 32, ROWB = 64;                 // 64-byte LDS rows (32 bf16)
 constexpr int WTM = 2;
@@ -219,8 +214,8 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
 #pragma unroll
             for (int it = 0; it < NPRE; ++it) {
                 const int m = min(m0 + e_rbase + it * RPI, p.M - 1);      // rows past M repeat the last one (never stored)
-                rpre_h[it] = ld16(rs + (long long)m * p.ldres + e_n, p.nt_stream);
-                rpre_l[it] = ld16(rs + p.plRes + (long long)m * p.ldres + e_n, p.nt_stream);
+                rpre_h[it] = ld16(rs + (long long)m * p.ldres + e_n);
+                rpre_l[it] = ld16(rs + p.plRes + (long long)m * p.ldres + e_n);
             }
         }
     };
@@ -494,8 +489,8 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int m = min(m0 + e_rbase + (U + u) * RPI, p.M - 1);
-            nh[u] = ld16(resh + (long long)m * p.ldres + e_n, p.nt_stream);
-            nl[u] = ld16(resh + p.plRes + (long long)m * p.ldres + e_n, p.nt_stream);
+            nh[u] = ld16(resh + (long long)m * p.ldres + e_n);
+            nl[u] = ld16(resh + p.plRes + (long long)m * p.ldres + e_n);
         }
     }
 #pragma unroll
@@ -511,8 +506,8 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
                 if (res_nxt && c0 == U) { rh[u] = nh[u]; rl[u] = nl[u]; continue; }
             }
             if (resh && m < p.M) {
-                rh[u] = ld16(resh + (long long)m * p.ldres + e_n, p.nt_stream);
-                rl[u] = ld16(resh + p.plRes + (long long)m * p.ldres + e_n, p.nt_stream);
+                rh[u] = ld16(resh + (long long)m * p.ldres + e_n);
+                rl[u] = ld16(resh + p.plRes + (long long)m * p.ldres + e_n);
             }
         }
 #pragma unroll
@@ -546,8 +541,8 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
             if (ch) {
                 u32x4 hi, lo;
                 x3_split8<F16>(v, hi, lo);
-                st16(ch + (long long)m * p.ldc + e_n, hi, p.nt_stream);
-                st16(ch + p.plC + (long long)m * p.ldc + e_n, lo, p.nt_stream);
+                st16(ch + (long long)m * p.ldc + e_n, hi);
+                st16(ch + p.plC + (long long)m * p.ldc + e_n, lo);
             }
         }
     }
@@ -634,18 +629,12 @@ int sq_launch_gemm_x3(const GemmArgs& a_in, hipStream_t stream) {
         snprintf(name, sizeof(name), "%s_%s_M%d_N%d_K%d", a.conv ? "conv" : "gemm", a.x3_f16 ? "f16x3" : "bf16x3", a.M, a.N, a.K);
         prof = sq_prof_begin(name, flops, bytes, stream);
     }
-    // streaming policy for the residual reads and the plane stores: an experiment switch (SQ_X3_NT=1)
-    static int env_nt = -2;
-    if (env_nt == -2) { const char* e = getenv("SQ_X3_NT"); env_nt = e ? atoi(e) : -1; }
-    a.nt_stream = env_nt > 0 ? 1 : 0;             // default off: same-box A/B of the pipeline 34.1 / 34.4 (off) vs 34.1 / 34.1 slides/s (on) -- only chain_x3w.hip gains from it
-    static const bool lockstep = sq_env_flag("SQ_X3_LOCKSTEP");     // A/B switch: the one-barrier-per-tile schedule (all waves in step)
-    static int env_max_k = -1;                                       // products with K up to this take the 128-row, two-blocks-per-CU shape
-    if (env_max_k < 0) { const char* e = getenv("SQ_X3_SMALL_MAXK"); env_max_k = e ? atoi(e) : 256; }
-    const int small_max_k = g_x3_small_max_k >= 0 ? g_x3_small_max_k : env_max_k;
+    // products with K up to this take the 128-row, two-blocks-per-CU shape (sq_dbg_set key 7 overrides: probes; 512 ... 2048 measured level in the pipeline)
+    const int small_max_k = g_x3_small_max_k >= 0 ? g_x3_small_max_k : 256;
     const int rc = dual ? (a.x3_f16 ? launch_x3_dual<true>(a, stream) : launch_x3_dual<false>(a, stream))
                  : (g_x3_halo != 0 && sq_conv_halo_x3_eligible(a)) ? sq_launch_conv_halo_x3(a, stream)
                  : (a.K <= small_max_k || (a.N <= 64 && small_max_k > 0)) ? launch_x3_fmt<128, false>(a, stream)
-                 : lockstep ? launch_x3_fmt<256, false>(a, stream) : launch_x3_fmt<256, true>(a, stream);
+                 : launch_x3_fmt<256, true>(a, stream);
     if (prof >= 0) sq_prof_end(prof, stream);
     return rc;
 }

@@ -783,8 +783,7 @@ extern "C" int sq_kmeans_fit(const float* X, int S, int n, int D, int k, int fir
     SQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(km_dist_f32_kernel, dim3(n, S), dim3(256), 0, st, b.G, b.dist32, n);
     SQ_LAUNCH_CHECK();
-    const bool few_waves = !sq_env_flag("SQ_KM_SEED_1024");
-    if (n <= KM_THREADS && few_waves)       // 4 waves x 4 points per thread: cheaper barriers and wave exchanges than 16 waves x 1
+    if (n <= KM_THREADS)       // 4 waves x 4 points per thread: cheaper barriers and wave exchanges than 16 waves x 1
         hipLaunchKernelGGL(km_seed_kernel<4>, dim3(S), dim3(256), 0, st, b.dist32, uniforms, first_center, n, k, n_local_trials, b.seeds);
     else if (n <= KM_THREADS)
         hipLaunchKernelGGL(km_seed_kernel<1>, dim3(S), dim3(KM_THREADS), 0, st, b.dist32, uniforms, first_center, n, k, n_local_trials, b.seeds);

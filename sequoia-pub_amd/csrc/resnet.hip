@@ -361,7 +361,7 @@ extern "C" int sq_resnet50_extract_checked(int dtype, const void* weights, const
     // launch (bottleneck.hip) -- that block's conv1 output then already sits in act[t1i] when its turn comes.
     const bool fuse56 = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && (128 + 2 * H + 2) * 128 <= 32768;
     const bool fuse_chain = lp && !sq_env_flag("SQ_RESNET_NO_FUSE") && !sq_env_flag("SQ_RESNET_NO_CHAIN");
-    const bool fuse_chain256 = fuse_chain && !sq_env_flag("SQ_RESNET_NO_CHAIN256");
+    const bool fuse_chain256 = fuse_chain;
     int xi = 1, ci = 1, t1i = stem_t1 ? 2 : -1;
     const int blocks[4] = {3, 4, 6, 3};
     for (int li = 0; li < 4; ++li)
@@ -428,8 +428,7 @@ extern "C" int sq_resnet50_extract_checked(int dtype, const void* weights, const
             // read back; t1' lands in the buffer conv1's output occupied (dead once conv2 has read it)
             if (x3 && !has_ds && !sq_env_flag("SQ_RESNET_NO_CHAINW") && c3.k == 1 && c3.cout == 4 * c3.cin && cnext < SQ_RESNET50_CONVS &&
                 lay.conv[cnext].k == 1 && lay.conv[cnext].stride == 1 && lay.conv[cnext].cin == c3.cout &&
-                sq_chain_x3w_eligible(c3.cin, lay.conv[cnext].cout) &&
-                !(lay.conv[cnext].cout != c3.cin && sq_env_flag("SQ_CHAINW_NO_2C"))) {       // (A/B switch: the pair that ends layer 2, next width 2 C)
+                sq_chain_x3w_eligible(c3.cin, lay.conv[cnext].cout)) {
                 const sq_conv_desc& n1 = lay.conv[cnext];
                 auto rest = [&](const sq_conv_desc& d) { return w_bytes_total - (size_t)d.w_off * es; };
                 RUN(sq_launch_chain_x3w(f16, c3.cin, (const uint16_t*)t2, act_plane, (const uint16_t*)x, act_plane, (uint16_t*)y, act_plane,

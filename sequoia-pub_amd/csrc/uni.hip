@@ -449,7 +449,7 @@ extern "C" int sq_uni_forward(const sq_uni_config* c, int dtype, const float* pa
     auto Bf = [&](int64_t off) { return bias_exec + off; };
     auto grid_for = [](size_t work) { size_t nb = (work + 255) / 256; return (int)(nb > 65535 ? 65535 : (nb ? nb : 1)); };
     auto ln = [&](const float* x, size_t stride, int64_t g, int64_t b, void* y, int ydt, int R) -> int {
-        const bool v8 = D == 1024 && stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)Pf(g) | (uintptr_t)Pf(b)) & 15) == 0 && !sq_env_flag("SQ_UNI_LN_GENERIC");
+        const bool v8 = D == 1024 && stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)Pf(g) | (uintptr_t)Pf(b)) & 15) == 0;
         if (v8 && ydt == SQ_BF16) hipLaunchKernelGGL((uni_ln8_kernel<bf16_t, 2>), dim3((R + 3) / 4), dim3(256), 0, s, x, stride, Pf(g), Pf(b), (bf16_t*)y, R, 1e-6f);
         else if (v8) hipLaunchKernelGGL((uni_ln8_kernel<float, 2>), dim3((R + 3) / 4), dim3(256), 0, s, x, stride, Pf(g), Pf(b), (float*)y, R, 1e-6f);
         else if (ydt == SQ_BF16) hipLaunchKernelGGL(uni_ln_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, x, stride, Pf(g), Pf(b), (bf16_t*)y, R, D, 1e-6f);
@@ -475,7 +475,7 @@ extern "C" int sq_uni_forward(const sq_uni_config* c, int dtype, const float* pa
 
     const size_t att_lds = ((size_t)T * DH * 2 + (size_t)T * (DH + 1) + 4 * ATT_MAXT) * sizeof(float);
     const size_t att_mfma_lds = 2 * 256 * 128 + 4 * 4096;
-    const bool valu_attn = sq_env_flag("SQ_UNI_VALU_ATTN") || (T + 31) / 32 * 32 > 256;   // A/B knob; the K / V images hold <= 256 keys
+    const bool valu_attn = (T + 31) / 32 * 32 > 256;   // the MFMA core's K / V images hold <= 256 keys
     static SqDevOnce attr;       // hipFuncSetAttribute is per device
     if (attr.needed()) {
         SQ_HIP_CHECK(hipFuncSetAttribute((const void*)uni_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_mfma_lds));

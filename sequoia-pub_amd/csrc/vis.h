@@ -52,8 +52,5 @@ inline bool sq_vis_lean_stream(int dtype) {
     return dtype == SQ_BF16 && !sq_env_flag("SQ_VIS_FP32_STREAM");      // (read per call: tests flip it inside one process)
 }
 
-// dtype of the saved GELU pre-activations (U, P): the operand dtype; SQ_F32_PREACT=1 keeps fp32 (A/B knob)
-inline int sq_vis_preact_dtype(int dtype) {
-    static const int force32 = sq_env_flag("SQ_F32_PREACT") ? 1 : 0;
-    return force32 ? SQ_F32 : dtype;
-}
+// dtype of the saved GELU pre-activations (U, P): the operand dtype
+inline int sq_vis_preact_dtype(int dtype) { return dtype; }

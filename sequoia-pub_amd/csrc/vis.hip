@@ -187,7 +187,7 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
         }
         if (int e = sq_k_token_mean_any(stream16 ? Xin_t : (const void*)Xin, stream16 ? SQ_BF16 : SQ_F32, w.Xbar32[s],
                                         lp ? (bf16_t*)w.Xbar[s] : nullptr, B, N, D, s2)) return e;
-        if (lp && !sq_env_flag("SQ_FWD_NO_FUSED_SUMMARY")) {
+        if (lp) {
             // Sm = Xbar Ws^T + bs;  Ts = GELU(LN64(Sm));  Cs = Ts_h Wc_h[:, 64:]^T + bc_h  -- one launch (summary.hip)
             if (int e = sq_launch_summary_fwd(w.Xbar[s], W(L.s_w), Pf(L.s_b), Pf(L.lns_g), Pf(L.lns_b), W(L.c_w), Pf(L.c_b), w.Sm[s],
                                               w.Ts[s], w.Cs[s], B, D, H, s2)) return e;

@@ -309,7 +309,7 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
         const sq_vis_layer_offsets& L = lay.layer[l];
         LayerG lg = b.lg[l];
         sq_colsum_jobs csj;              // this layer's small column sums (3 LayerNorms + the combiner bias): one launch
-        sq_colsum_jobs* defer = sq_env_flag("SQ_BWD_NO_DEFER") ? nullptr : &csj;
+        sq_colsum_jobs* defer = &csj;
         if (!lp) { lg.dXin_lp = dXcur; lg.dX1_lp = dXoth; }
         // ---------------- FeedForward: X2 = GELU(LN(X1) W1^T + b1) W2^T + b2 + X1 ----------------
         RUN(ready());

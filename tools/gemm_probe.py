@@ -70,22 +70,6 @@ if __name__ == "__main__":
         for M, N, K in [(50432, 4096, 1024), (50432, 3072, 1024)]:           # bf16 output (what the UNI blocks write)
             probe(M, N, K, _lib.SQ_BF16, tiles=(55, 88), dbgs=(0,), out_bf16=True, scheds=(0, 1))
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "p8x":
-        # start-up skew by XCD parity (negative knob values): odd XCDs start late, blocks of one XCD stay in step
-        for out_bf16 in (False, True):
-            for M, N, K in [(50432, 4096, 1024), (102400, 1024, 1024), (50432, 1024, 4096)]:
-                for skew in (0, -8000, -16000, -30000, -60000, 0):
-                    lib.sq_dbg_set(12, skew)
-                    print("xcd-parity skew", -skew, "bf16 out" if out_bf16 else "fp32 out")
-                    probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0,), scheds=(1,), out_bf16=out_bf16)
-        lib.sq_dbg_set(12, -1)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "p8nt":
-        # non-temporal result stores (dbg 16; dbg 32 = the same DBG build with plain stores, so that the two arms share one binary)
-        for out_bf16 in (False, True):
-            for M, N, K in [(50432, 4096, 1024), (50432, 1024, 1024), (102400, 1024, 1024), (8192, 8192, 8192)]:
-                probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(32, 16, 32, 16), scheds=(1,), out_bf16=out_bf16)
-        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "p8m":
         # mid-size products: where does the 256 x 256 kernel (tile 88) start to beat the engine's pick (tile 0 = the kernel it replaces
         # below SQ_GEMM_P8_MIN_TILES tiles)?  tiles of 256 x 256 in brackets
@@ -113,14 +97,10 @@ if __name__ == "__main__":
         lib.sq_dbg_set(13, -1)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "p8p":
-        # persistent form of gemm_p8.hip (sched 1) against one block per tile (sched 0), and its start-up skew (cycles per step; 0 = none)
+        # persistent form of gemm_p8.hip (sched 1) against one block per tile (sched 0)
         for out_bf16 in (False, True):
             for M, N, K in [(50432, 4096, 1024), (50432, 1024, 4096), (50432, 3072, 1024), (50432, 1024, 1024), (102400, 1024, 1024), (102400, 2048, 2048), (8192, 8192, 8192)]:
-                for skew in (-1, 0, 6000, 24000, -1):
-                    lib.sq_dbg_set(12, skew)
-                    print("skew", skew, "bf16 out" if out_bf16 else "fp32 out")
-                    probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0,), scheds=(0, 1) if skew == -1 else (1,), out_bf16=out_bf16)
-        lib.sq_dbg_set(12, -1)
+                probe(M, N, K, _lib.SQ_BF16, tiles=(88,), dbgs=(0,), scheds=(0, 1, 0, 1), out_bf16=out_bf16)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "p8g":
         # tile-walk group height of gemm_p8.hip (1 = row-major inside an XCD's run)
