@@ -294,6 +294,10 @@ def measure_traffic(roof, args, recs=()):
     roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate one-slide passes of this build in child processes, "
                               f"{round(time.time() - t0, 1)} s")
     roof["traffic_by_class"] = by
+    # what the counters see: requests that leave an XCD's L2.  Re-reads another XCD fetched a moment ago are served by the 256 MB
+    # memory-side cache, not by DRAM -- a ratio above 1 is fabric traffic (operand panels / halo rows re-read under a second L2),
+    # not necessarily DRAM traffic (the 56x56 tails went from 1.17-1.27 to 1.01-1.03 at an unchanged rate)
+    roof["traffic_note"] = "L2-miss bytes at the XCDs (FETCH_SIZE / WRITE_SIZE): includes re-reads the memory-side cache serves"
     return True
 
 
