@@ -578,7 +578,7 @@ int sq_launch_chain_x3_c64(int f16, const uint16_t* t2, long long plT2, const ui
     a.w3_bytes = clamp(w3_bytes);
     a.xin = xin; a.plX = plX; a.wd = frag + FRAG_WD; a.bd = bd; a.csd = csd; a.wd_bytes = clamp(wd_bytes);
     a.t1 = t1; a.plT1 = plT1; a.w2 = frag + FRAG_W2; a.b2 = b2; a.cs2 = cs2; a.w2_bytes = (uint32_t)((FRAG - FRAG_W2) * 2); a.W = W; a.HW = HW; a.dbg = g_dbg;
-    { static int env_walk = -1; if (env_walk < 0) { const char* e = getenv("SQ_X3_TAIL_XCD_WALK"); env_walk = e ? atoi(e) : 64; } a.xcd_walk = tail ? env_walk : 0; }
+    { const char* e = getenv("SQ_X3_TAIL_XCD_WALK"); a.xcd_walk = tail ? (e ? atoi(e) : 64) : 0; }      // (read per launch: the tests flip it inside one process)
     using I64 = std::integral_constant<int, 64>; using I128 = std::integral_constant<int, 128>;
     using T = std::true_type; using F = std::false_type;
     auto pick_tail = [&](auto n2c, auto f16c, auto dsc) {

@@ -290,3 +290,24 @@ def test_resnet50_x3_fused_chain_is_bit_identical(monkeypatch, mode):
     assert torch.isfinite(outs["tail"][0]).all()
     for tag in ("tail", "no_chainw", "no_stem_reduce", "chain", "chain_no_ds", "no_dual", "dual_everywhere"):
         assert torch.equal(outs[tag][0], outs["plain"][0]) and torch.equal(outs[tag][1], outs["plain"][1]), tag
+
+
+@pytest.mark.parametrize("mode", ["f16x3"])
+def test_tail_tile_walk_does_not_change_a_bit(monkeypatch, mode):
+    """The 56 x 56 tails walk their tiles in chunks of 64 per XCD (chain_x3.hip: halo rows shared under one L2).  The walk only
+    renames tiles: 11 patches = 539 tiles of 64 pixels (512 walked in chunks, the ragged 27 in plain order), 6 patches of 256
+    px = 384 tiles (chunks of 16: walked; 64: plain order) -- chunked, one run per XCD and plain order give the same bits."""
+    _lib.require_gpu()
+    m, sd = _model(mode)
+    p = torch.from_numpy(synth.patches_u8(11, n_patches=11, size=224)).cuda()
+    p256 = torch.from_numpy(synth.patches_u8(12, n_patches=6, size=256)).cuda()
+    outs = {}
+    for walk in ("0", "64", "16", "1"):
+        monkeypatch.setenv("SQ_X3_TAIL_XCD_WALK", walk)
+        outs[walk] = (m.extract_patches_u8(p), m.extract_patches_u8(p256))
+    monkeypatch.delenv("SQ_X3_TAIL_XCD_WALK")
+    outs["default"] = (m.extract_patches_u8(p), m.extract_patches_u8(p256))
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs["0"][0]).all() and torch.isfinite(outs["0"][1]).all()
+    for k in ("64", "16", "1", "default"):
+        assert torch.equal(outs[k][0], outs["0"][0]) and torch.equal(outs[k][1], outs["0"][1]), k
