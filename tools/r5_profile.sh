@@ -21,9 +21,9 @@ python tools/pmc_summary.py r05_pipeline_f16x3 gpurun_out/profiles_r05/r05_pipel
   "conv_f16x3_M196000_N256_K2304=conv_halo_x3_kernel<2, 320, true, true>:784384" \
   "conv_f16x3_M784000_N128_K1152=conv_halo_x3_kernel<2, 320, true, true>:1568256" \
   "conv_f16x3_M49000_N512_K4608=conv_halo_x3_kernel<2, 320, true, true>:393216" \
-  "tail_f16x3_c64_cn64_P3136000=chain_x3_kernel<64, true, false, true>:12544000" \
-  "tail_f16x3_c64_cn64_ds_P3136000=chain_x3_kernel<64, true, true, true>:12544000" \
-  "tail_f16x3_c64_cn128_P3136000=chain_x3_kernel<128, true, false, true>:12544000" \
+  "tail_f16x3_c64_cn64_P3136000=chain_x3_kernel<64, true, false, true, false>:12544000" \
+  "tail_f16x3_c64_cn64_ds_P3136000=chain_x3_kernel<64, true, true, true, false>:12544000" \
+  "tail_f16x3_c64_cn128_P3136000=chain_x3_kernel<128, true, false, true, false>:12544000" \
   "chainw_f16x3_c256_cn256_P196000=chain_x3w_kernel<256, 256, true, false>:784384" \
   "chainw_f16x3_c128_cn128_P784000=chain_x3w_kernel<128, 128, true, false>:3136000" \
   "chainw_f16x3_c128_cn256_P784000=chain_x3w_kernel<128, 256, true, false>:3136000" \
