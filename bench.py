@@ -837,7 +837,7 @@ def main():
     ap.add_argument("--uni-sub-batch", type=int, default=0, help="pipeline workload, UNI embedder: patches per launch group (default 1000 in bf16 "
                     "-- 6.09 / 6.38 / 6.58 slides/s at 256 / 500 / 1000 -- and 256 in fp32: the 2 GiB descriptor limit)")
     ap.add_argument("--grid", type=int, nargs=2, default=[250, 200], help="spatial workload: tile grid")
-    ap.add_argument("--batch-windows", type=int, default=2048, help="spatial workload: windows per ViS forward (2048: 452 ms per slide against 470 at 1024 and 505 at 512 -- more tiles per launch of the 256 x 256 GEMM)")
+    ap.add_argument("--batch-windows", type=int, default=8192, help="spatial workload: windows per ViS forward (8192: 438 ms per slide against 444 at 2048, 470 at 1024 and 505 at 512 -- more tiles per launch of the 256 x 256 GEMM)")
     ap.add_argument("--embedder", default="resnet", choices=["resnet", "uni"], help="pipeline workload: patch embedder")
     ap.add_argument("--no-stream", action="store_true", help="pipeline workload: finish every step's slides before the next step starts")
     ap.add_argument("--resident", action="store_true", help="pipeline workload: patches already in HBM when the timed region starts "
