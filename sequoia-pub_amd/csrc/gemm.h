@@ -62,6 +62,12 @@ struct GemmArgs {
     const float* bias2 = nullptr; const float* colscale2 = nullptr;
     int dH = 0, dW = 0, dOH = 0, dOW = 0, dstride = 1;
     int tile_group_m = 0;              // gemm_p8.hip: tile rows per group of the tile walk (set by its launcher)
+    // gemm_p8.hip only (sq_launch_gemm_p8 directly): the ViS combiner in the f projection's epilogue (src/tformer_lin.py:20-25).  With
+    // ln64_g / ln64_b and act = GELU set, C receives  GELU( GELU(LN64(A.B^T + bias))_h . comb_w_h[:, 0:64]^T + comb_rb[m / comb_rpg, h] )
+    // per head h = 64 columns: the per-head 64 x 64 product runs on the wave's LDS slab, Lf is never written
+    const void* comb_w = nullptr;      // bf16 [N / 64][64][128]: row o of head h = the combiner weight row, its first 64 columns apply to Lf
+    const float* comb_rb = nullptr;    // f32 [ceil(M / comb_rpg), N] (comb_ldrb): the summary half's product + the combiner bias (Cs)
+    int comb_ldrb = 0, comb_rpg = 1;
     int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };
 
@@ -72,6 +78,7 @@ static __device__ __forceinline__ P sq_group_pick(P const (&a)[4], int i) { retu
 
 // dtype: SQ_F32 (v_mfma_f32_32x32x2_f32, exact fp32) or SQ_BF16 (v_mfma_f32_32x32x16_bf16)
 int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream);
+bool sq_gemm_takes_p8_256(const GemmArgs& a);      // bf16: would sq_launch_gemm run gemm_p8.hip's 256 x 256 kernel (the one with the combiner epilogue)?
 // split-bf16 product (gemm_x3.hip): hi/lo bf16 planes, three bf16 MFMAs per product, fp32 accumulation; bias / residual / ReLU only
 int sq_launch_gemm_x3(const GemmArgs& a, hipStream_t stream);
 // TN product for weight gradients:  C[M,N] = alpha * sum_k A[k, M-index] * B[k, N-index]

@@ -27,6 +27,7 @@ int sq_launch_conv_halo(const GemmArgs& a, hipStream_t stream);
 bool sq_gemm_w4_eligible(const GemmArgs& a, int dtype);
 int sq_launch_gemm_w4(const GemmArgs& a, hipStream_t stream);
 bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype);
+int sq_gemm_p8_shape(const GemmArgs& a, int dtype);
 int sq_launch_gemm_p8(const GemmArgs& a, hipStream_t stream);
 bool sq_gemm_ring_eligible(const GemmArgs& a, int dtype);
 int sq_launch_gemm_ring(const GemmArgs& a, hipStream_t stream);
@@ -598,6 +599,28 @@ extern "C" int sq_dbg_set(int key, int value) {
     return SQ_OK;
 }
 
+// 16-byte epilogue accesses need every leading dimension / base / batch stride aligned
+int sq_gemm_vec_epi(const GemmArgs& a) {
+    auto al = [](const void* ptr, int ld, long long st, int elem) {
+        return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
+    };
+    auto al8 = [&](const void* ptr, int ld, long long st) { return al(ptr, ld, st, 2); };   // bf16 rows: 16-byte accesses
+    bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, a.pre_dtype == SQ_F32 ? 4 : 2) &&
+              al(a.gelu_grad_of, a.ldgg, a.sGg, a.gg_dtype == SQ_F32 ? 4 : 2) && al8(a.C2, a.ldc2, a.sC2);
+    ok = ok && (a.out_dtype == SQ_F32 ? al(a.C, a.ldc, a.sC, 4) : al8(a.C, a.ldc, a.sC));
+    ok = ok && (a.res_dtype == SQ_F32 ? al(a.res, a.ldres, a.sRes, 4) : al8(a.res, a.ldres, a.sRes));
+    return ok ? 1 : 0;
+}
+
+// Would sq_launch_gemm hand this bf16 product to gemm_p8.hip's 256 x 256 kernel?  (vis.hip asks before it sets GemmArgs::comb_w:
+// only that kernel has the combiner epilogue.)
+bool sq_gemm_takes_p8_256(const GemmArgs& a) {
+    GemmArgs av = a;
+    av.vec_epi = sq_gemm_vec_epi(a);
+    av.splitk = 1;
+    return g_force_tile == 0 && !a.conv && a.N % 8 == 0 && sq_gemm_p8_shape(av, SQ_BF16) == 256;
+}
+
 int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
     const int epc = dtype == SQ_BF16 ? 8 : 4;
     SQ_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -616,17 +639,7 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
         return SQ_ERR_ARG;
     }
     GemmArgs av = a;
-    {   // 16-byte epilogue accesses need every leading dimension / base / batch stride aligned
-        auto al = [](const void* ptr, int ld, long long st, int elem) {
-            return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld * elem) % 16 == 0 && ((st * elem) % 16) == 0);
-        };
-        auto al8 = [&](const void* ptr, int ld, long long st) { return al(ptr, ld, st, 2); };   // bf16 rows: 16-byte accesses
-        bool ok = al(a.bias, 4, a.sBias, 4) && al(a.rowbias, a.ldrb, a.sRb, 4) && al(a.Cpre, a.ldpre, a.sPre, a.pre_dtype == SQ_F32 ? 4 : 2) &&
-                  al(a.gelu_grad_of, a.ldgg, a.sGg, a.gg_dtype == SQ_F32 ? 4 : 2) && al8(a.C2, a.ldc2, a.sC2);
-        ok = ok && (a.out_dtype == SQ_F32 ? al(a.C, a.ldc, a.sC, 4) : al8(a.C, a.ldc, a.sC));
-        ok = ok && (a.res_dtype == SQ_F32 ? al(a.res, a.ldres, a.sRes, 4) : al8(a.res, a.ldres, a.sRes));
-        av.vec_epi = ok ? 1 : 0;
-    }
+    av.vec_epi = sq_gemm_vec_epi(a);
     int prof = -1;
     if (sq_prof_on()) {
         // algorithmic work of this launch: 2*M*N*K flops; operands read once + output written once
@@ -651,7 +664,14 @@ int sq_launch_gemm(const GemmArgs& a, int dtype, hipStream_t stream) {
                    "gemm: the fused LayerNorm(64) epilogue needs N %% 64 == 0 (N=%d), 16-byte aligned operands and a plain A", av.N);
         av.splitk_ws = nullptr;            // the whole row group must be in one block: no K-slices
     }
-    const int rc = dtype == SQ_BF16 ? launch_t<bf16_t>(av, stream) : launch_t<float>(av, stream);
+    int rc;
+    if (av.comb_w) {                       // the ViS combiner epilogue lives in gemm_p8.hip only: the caller has asked sq_gemm_takes_p8_256
+        SQ_REQUIRE(dtype == SQ_BF16 && sq_gemm_takes_p8_256(a), "gemm: the combiner epilogue (comb_w) needs a bf16 product gemm_p8.hip's 256 x 256 kernel takes");
+        av.splitk = 1;
+        rc = sq_launch_gemm_p8(av, stream);
+    } else {
+        rc = dtype == SQ_BF16 ? launch_t<bf16_t>(av, stream) : launch_t<float>(av, stream);
+    }
     if (prof >= 0) sq_prof_end(prof, stream);
     return rc;
 }

@@ -299,6 +299,16 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
         bf16_t* c16p = p.out_dtype == SQ_BF16 ? reinterpret_cast<bf16_t*>(p.C) + (long long)z * p.sC : nullptr;
         float* cpre32 = (p.Cpre && p.pre_dtype == SQ_F32) ? reinterpret_cast<float*>(p.Cpre) + (long long)z * p.sPre : nullptr;
         bf16_t* cpre16 = (p.Cpre && p.pre_dtype == SQ_BF16) ? reinterpret_cast<bf16_t*>(p.Cpre) + (long long)z * p.sPre : nullptr;
+        // EPI & 8: the ViS combiner on the slab (GemmArgs::comb_w).  B fragments of this wave's head: n-fragment jj (16 outputs) x k-step
+        // ks (32 of the 64 local inputs), lane (n = f_r, k group f_kg) -- 8 KiB of L2-resident weights per wave and tile
+        u32x4 wcf[4][2] = {};
+        if constexpr ((EPI & 8) != 0) {
+            const bf16_t* wsrc = reinterpret_cast<const bf16_t*>(p.comb_w) + (size_t)((n0_ + wc * 64) >> 6) * (64 * 128);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) wcf[jj][ks] = *reinterpret_cast<const u32x4*>(wsrc + (16 * jj + f_r) * 128 + 32 * ks + 8 * f_kg);
+        }
         auto ld8 = [&](const float* s32, const bf16_t* s16, long long off, float (&d)[8]) {
             if (s16) {
                 const u32x4 tt = *reinterpret_cast<const u32x4*>(s16 + off);
@@ -398,6 +408,84 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                 if (p.C2) *reinterpret_cast<u32x4*>(p.C2 + (long long)z * p.sC2 + (long long)m * p.ldc2 + e_n) = packed;   // bf16 operand copy
             }
         };
+        // one m-fragment through the combiner: LayerNorm(64) + GELU rows -> bf16 A tile on the slab (two [16][32] sub-tiles in the
+        // operand buffers' format) -> 8 MFMAs against the head's fragments -> fp32 slab again -> + Cs row, GELU, 16-byte stores.
+        // The slab is private to the wave and LDS operations of a wave execute in order: no barrier anywhere.
+        auto slab_out_comb = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int mrow0 = m0_ + wr * (MF * 16) + i * 16;
+            char* const sb = reinterpret_cast<char*>(slab);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(f_kg * 4 + r) * 64 + j * 16 + f_r] = acc[i][j][r];
+            float v[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = u * 8 + e_r8;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8 + 4);
+                const float t[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = p.alpha * t[e] + bias8[e];
+                // LayerNorm(64) as in the plain epilogue below (two-pass, eps 1e-5), then GELU: Lf
+                float sm = ((v[u][0] + v[u][1]) + (v[u][2] + v[u][3])) + ((v[u][4] + v[u][5]) + (v[u][6] + v[u][7]));
+                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                const float mean = sm * (1.0f / 64.0f);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[u][e] -= mean; q += v[u][e] * v[u][e]; }
+                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = sq_gelu<true>(v[u][e] * rstd * lng[e] + lnb[e]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {            // (behind BOTH read passes: the A tile lies over fp32 rows 0-7)
+                const int row = u * 8 + e_r8;
+                const u32x4 packed = {pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], v[u][3]), pack_bf16x2(v[u][4], v[u][5]), pack_bf16x2(v[u][6], v[u][7])};
+                *reinterpret_cast<u32x4*>(sb + (e_c8 >> 2) * 1024 + ((row * 64 + (e_c8 & 3) * 16) ^ ((row >> 3) << 5))) = packed;
+            }
+            const u32x4 af0 = lds_read128(sb + f_byte), af1 = lds_read128(sb + 1024 + f_byte);
+            f32x4v o[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                union { u32x4 u; bf16x8 h; } ua, ub;
+                o[jj] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                ua.u = af0; ub.u = wcf[jj][0];
+                o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.h, ub.h, o[jj], 0, 0, 0);
+                ua.u = af1; ub.u = wcf[jj][1];
+                o[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.h, ub.h, o[jj], 0, 0, 0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(f_kg * 4 + r) * 64 + jj * 16 + f_r] = o[jj][r];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = u * 8 + e_r8;
+                const int m = mrow0 + row;
+                if (m >= p.M || (dbg & 1)) continue;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8 + 4);
+                const float* rb = p.comb_rb + (long long)(m / p.comb_rpg) * p.comb_ldrb + e_n;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rb), r1 = *reinterpret_cast<const f32x4*>(rb + 4);
+                float w8[8] = {a0[0] + r0[0], a0[1] + r0[1], a0[2] + r0[2], a0[3] + r0[3], a1[0] + r1[0], a1[1] + r1[1], a1[2] + r1[2], a1[3] + r1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w8[e] = sq_gelu<true>(w8[e]);
+                *reinterpret_cast<u32x4*>(c16p + (long long)m * p.ldc + e_n) =
+                    u32x4{pack_bf16x2(w8[0], w8[1]), pack_bf16x2(w8[2], w8[3]), pack_bf16x2(w8[4], w8[5]), pack_bf16x2(w8[6], w8[7])};
+            }
+        };
+        if constexpr ((EPI & 8) != 0) {
+            slab_out_comb(std::integral_constant<int, 0>{}); slab_out_comb(std::integral_constant<int, 1>{});
+            slab_out_comb(std::integral_constant<int, 2>{}); slab_out_comb(std::integral_constant<int, 3>{});
+            if constexpr (MF == 8) {
+                slab_out_comb(std::integral_constant<int, 4>{}); slab_out_comb(std::integral_constant<int, 5>{});
+                slab_out_comb(std::integral_constant<int, 6>{}); slab_out_comb(std::integral_constant<int, 7>{});
+            }
+            return;
+        }
         slab_out(std::integral_constant<int, 0>{}); slab_out(std::integral_constant<int, 1>{});
         slab_out(std::integral_constant<int, 2>{}); slab_out(std::integral_constant<int, 3>{});
         if constexpr (MF == 8) {
@@ -496,6 +584,7 @@ int launch_p8(const GemmArgs& a, dim3 grid, hipStream_t stream) {
 }
 template <bool PERSIST, int BNT>
 int launch_p8_pick(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.comb_w) return launch_p8<13, PERSIST, false, BNT>(a, grid, stream);          // LayerNorm(64) + GELU + the ViS combiner
     if (a.dbg) return a.act == SQ_ACT_GELU ? launch_p8<1, PERSIST, true, BNT>(a, grid, stream) : launch_p8<0, PERSIST, true, BNT>(a, grid, stream);
     if (a.ln64_g) return launch_p8<5, PERSIST, false, BNT>(a, grid, stream);          // LayerNorm(64) [+ GELU when act says so]
     if (a.gelu_grad_of) return launch_p8<2, PERSIST, false, BNT>(a, grid, stream);    // GELU' multiply (backward pass)
@@ -519,6 +608,10 @@ int sq_launch_gemm_p8(const GemmArgs& a_in, hipStream_t stream) {
     SQ_REQUIRE(!a.rowbias, "gemm_p8: no row-bias epilogue");
     SQ_REQUIRE(!(a.ln64_g && a.gelu_grad_of), "gemm_p8: LayerNorm(64) and GELU' epilogues cannot be combined");
     SQ_REQUIRE(a.K % 8 == 0, "gemm_p8: K=%d must be a multiple of 8 (16-byte operand chunks), also when the tile is forced", a.K);
+    SQ_REQUIRE(!a.comb_w || (a.comb_rb && a.ln64_g && a.ln64_b && a.act == SQ_ACT_GELU && a.out_dtype == SQ_BF16 && a.N % 256 == 0 && a.vec_epi &&
+                             !a.res && !a.rowbias && !a.Cpre && !a.C2 && !a.gelu_grad_of && a.batch == 1 && a.comb_rpg >= 1 && a.comb_ldrb % 4 == 0 &&
+                             ((uintptr_t)a.comb_w & 15) == 0 && ((uintptr_t)a.comb_rb & 15) == 0),
+               "gemm_p8: the combiner epilogue needs LayerNorm(64) + GELU, bf16 results, N %% 256 == 0, no residual / copies, 16-byte aligned operands");
     constexpr int env_gm = 8, env_persist = 1;
     a.tile_group_m = g_p8_group_m > 0 ? g_p8_group_m : env_gm;
     int bn = sq_gemm_p8_shape(a, SQ_BF16);

@@ -166,7 +166,10 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
     // layer inputs, X1 and the pre-LayerNorm(64) tensor F are stored in bf16 only (what the backward pass re-reads), fp32 master
     // weights and AdamW state stay.  SQ_VIS_FP32_STREAM=1 brings the fp32 stream back for both.
     const bool stream16 = sq_vis_lean_stream(dtype);
-    SqSideStream* fs = (lp && !sq_env_flag("SQ_FWD_ONE_STREAM")) ? sq_side_stream(1, 4 * SQ_MAX_DEPTH) : nullptr;
+    // the summary branch (token mean + three small products per layer) beside the f projection on a helper stream -- while the
+    // branch is small.  At the spatial path's batches (M = 204 800 rows and more) the token mean is a 0.4 GB pass that takes more
+    // from the projection than running it first costs: 437 -> 430 ms per 50 000-tile slide on ONE stream (round 5)
+    SqSideStream* fs = (lp && !sq_env_flag("SQ_FWD_ONE_STREAM") && M < 65536) ? sq_side_stream(1, 4 * SQ_MAX_DEPTH) : nullptr;
     hipStream_t s2 = fs ? fs->stream : st;
     int ev_next = 0;
 
@@ -208,6 +211,7 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             }
         }
         if (fs) { ev_cs = fs->events[ev_next++]; SQ_HIP_CHECK(hipEventRecord(ev_cs, s2)); }
+        bool combined = false;
         {   // Lf = GELU(LN64(F)),  F = X Wf^T + bf: LayerNorm + GELU in the epilogue (a head's 64 columns sit in 8
             // lanes of the staged tile); F itself is only written when the backward pass will need it
             GemmArgs g; g.A = Xin_t; g.lda = D; g.a_bytes = (size_t)M * D * es;
@@ -215,10 +219,19 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             g.ln64_g = Pf(L.lnf_g); g.ln64_b = Pf(L.lnf_b); g.act = SQ_ACT_GELU;
             if (save) { g.Cpre = w.F[s]; g.pre_dtype = stream16 ? SQ_BF16 : SQ_F32; g.ldpre = HD; }
             g.C = w.Lf[s]; g.out_dtype = dtype; g.ldc = HD; g.M = M; g.N = HD; g.K = D;
+            // Inference at large batch in bf16 mode (the spatial path; the summary branch ran first, on this stream): the combiner
+            //   O[m, h] = GELU(Lf[m, h] . Wc_h[:, 0:64]^T + Cs[slide(m), h])
+            // runs in THIS launch's epilogue (gemm_p8.hip: the head's 16 x 64 LayerNorm + GELU slab is the A operand of eight more
+            // MFMAs) -- Lf is neither written nor read and the batched 64 x 64 launch is gone (SQ_FWD_NO_FUSED_COMB=1: two launches)
+            if (lp && !save && !fs && HD % 256 == 0 && !sq_env_flag("SQ_FWD_NO_FUSED_COMB") && sq_gemm_takes_p8_256(g)) {
+                g.comb_w = W(L.c_w); g.comb_rb = w.Cs[s]; g.comb_ldrb = HD; g.comb_rpg = N;
+                g.C = w.O[s];
+                combined = true;
+            }
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
         if (ev_cs) SQ_HIP_CHECK(hipStreamWaitEvent(st, ev_cs, 0));
-        {   // O[m, h] = GELU(Lf[m, h] . Wc_h[:, 0:64]^T + Cs[slide(m), h])
+        if (!combined) {   // O[m, h] = GELU(Lf[m, h] . Wc_h[:, 0:64]^T + Cs[slide(m), h])
             GemmArgs g; g.A = w.Lf[s]; g.lda = HD; g.a_bytes = (size_t)M * HD * es; g.sA = SQ_HEAD_DIM;
             g.B = W(L.c_w); g.ldb = 2 * SQ_HEAD_DIM; g.b_bytes = Wrem(L.c_w); g.sB = SQ_HEAD_DIM * 2 * SQ_HEAD_DIM;
             g.rowbias = w.Cs[s]; g.ldrb = HD; g.sRb = SQ_HEAD_DIM; g.rows_per_group = N;

@@ -85,6 +85,36 @@ def test_vis_batch_sizes_vs_oracle(B):
     assert rel_err(out, ref) < 1e-4
 
 
+def test_combiner_in_the_f_projection_epilogue_matches_the_two_launches(monkeypatch):
+    """Inference in bf16 at large batch (the spatial path: M = B * 100 >= 65 536 rows): the per-head combiner runs in the f
+    projection's epilogue (gemm_p8.hip, GemmArgs::comb_w) and the summary branch ahead of it on the same stream.  Against the two
+    launches (SQ_FWD_NO_FUSED_COMB=1) on the same input -- same bf16 operands, the 64-deep sums in another MFMA shape: equal up to
+    the last bit of a bf16 now and then -- and, for the first slides, against the fp32 oracle at the bf16 tolerance.  A ragged last
+    tile (B = 701 -> 70 100 rows = 273 tiles of 256 + 212 rows) and D = 1024, depth 2."""
+    _lib.require_gpu()
+    cfg = dict(num_outputs=1000, input_dim=1024, depth=2, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=31), seed=32)
+    m = ViS(**cfg, device="cuda:0", compute_dtype="bf16")
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    B = 701
+    x = torch.from_numpy(synth.cluster_tokens(9, B, 1024))
+    xd = x.cuda()
+    with torch.no_grad():
+        monkeypatch.delenv("SQ_FWD_NO_FUSED_COMB", raising=False)
+        fused = m(xd).float().cpu()
+        fused2 = m(xd).float().cpu()
+        monkeypatch.setenv("SQ_FWD_NO_FUSED_COMB", "1")
+        plain = m(xd).float().cpu()
+        monkeypatch.delenv("SQ_FWD_NO_FUSED_COMB")
+        ref = vis_oracle.vis_forward(sd, x[:6]).numpy()
+    assert torch.isfinite(fused).all() and torch.equal(fused, fused2)
+    d = rel_err(fused.numpy(), plain.numpy())
+    print(f"combiner in the epilogue vs two launches: rel diff {d:.2e}, bit-equal outputs {float((fused == plain).float().mean()):.4f}; vs oracle {rel_err(fused[:6].numpy(), ref):.2e}")
+    assert d < 2e-3
+    assert rel_err(fused[:6].numpy(), ref) < TOL["bf16"] and rel_err(plain[:6].numpy(), ref) < TOL["bf16"]
+
+
 def test_no_cpu_fallback():
     m = ViS(8, 64, 1, 1, 64, 64, 64, device="cpu")
     with pytest.raises(_lib.SequoiaHipError):
