@@ -42,23 +42,59 @@ def enumerate_windows(xtf, ytf, stride, size=10, min_tiles=50):
     return members[keep], origins[keep]
 
 
-def tile_window_lists(members, n_tiles, device):
+def enumerate_windows_device(xtf, ytf, stride, device, size=10, min_tiles=50):
+    """enumerate_windows with the [W, size*size] member table built ON THE DEVICE and nothing the host waits for: the host
+    decides which windows are kept from an integral image of the occupancy grid (a few hundred microseconds), the device
+    unfolds the index grid, sorts every window's members (valid ascending, -1 last) and keeps those rows.  At BASELINE config 5's
+    size the numpy form is 50-140 ms of host time per slide during which the GPU idles.  Returns int64 [W, size*size] on `device`."""
+    xtf = np.asarray(xtf, dtype=np.int64)
+    ytf = np.asarray(ytf, dtype=np.int64)
+    max_x, max_y = int(xtf.max()), int(ytf.max())
+    if np.unique(xtf * (max_y + 1) + ytf).size != xtf.size:
+        raise ValueError("duplicate tile coordinates")
+    xs = np.arange(0, max_x, stride)
+    ys = np.arange(0, max_y, stride)
+    if len(xs) == 0 or len(ys) == 0:
+        return torch.zeros((0, size * size), dtype=torch.int64, device=device)
+    gx, gy = max_x + size + 1, max_y + size + 1
+    occ = np.zeros((gx + 1, gy + 1), dtype=np.int64)
+    occ[xtf + 1, ytf + 1] = 1
+    ii = occ.cumsum(0).cumsum(1)                                   # ii[a, b] = tiles with x < a and y < b
+    X, Y = xs[:, None], ys[None, :]
+    n_in = ii[X + size, Y + size] - ii[X, Y + size] - ii[X + size, Y] + ii[X, Y]
+    keep_idx = torch.from_numpy(np.flatnonzero((n_in > min_tiles).ravel())).to(device, non_blocking=True)
+    xy = torch.from_numpy(np.stack([xtf, ytf])).to(device, non_blocking=True)
+    grid = torch.full((gx, gy), -1, dtype=torch.int64, device=device)
+    grid[xy[0], xy[1]] = torch.arange(xtf.size, device=device)
+    win = grid.unfold(0, size, 1).unfold(1, size, 1)[0:max_x:stride, 0:max_y:stride]      # [len(xs), len(ys), size, size] view
+    members = win.reshape(len(xs) * len(ys), size * size)[keep_idx]
+    big = torch.iinfo(torch.int64).max
+    members = torch.sort(torch.where(members >= 0, members, big), dim=1).values     # (a window's tiles are distinct: no ties to order)
+    return torch.where(members == big, -1, members)
+
+
+def tile_window_lists(members, n_tiles, device, max_votes=None):
     """Invert members [W, 100] (window -> tiles) into int32 [n_tiles, V] (tile -> windows in visiting order, packed,
-    -1 padded); V = the largest number of windows any tile belongs to."""
+    -1 padded); V = the largest number of windows any tile belongs to, or `max_votes` when the caller knows a bound (then
+    nothing here waits for the device: no size depends on the data)."""
     mem = torch.as_tensor(members, device=device)
     W, S = mem.shape
-    win = torch.arange(W, device=device).unsqueeze(1).expand(W, S)
-    valid = mem >= 0
-    tiles, wins = mem[valid], win[valid]                        # row-major: already ascending in window id per tile
-    order = torch.sort(tiles, stable=True).indices
-    tiles, wins = tiles[order], wins[order]
-    counts = torch.bincount(tiles, minlength=n_tiles)
-    V = max(int(counts.max()), 1) if tiles.numel() else 1
+    win = torch.arange(W, device=device).unsqueeze(1).expand(W, S).reshape(-1)
+    flat = mem.reshape(-1)
+    tiles = torch.where(flat >= 0, flat, n_tiles)                 # padding goes to a dump row behind the last tile
+    tiles, order = torch.sort(tiles, stable=True)                 # row-major input: ascending window id inside every tile
+    wins = win[order]
+    counts = torch.bincount(tiles, minlength=n_tiles + 1)
+    if max_votes is None:
+        V = max(int(counts[:n_tiles].max()), 1) if W else 1
+    else:
+        V = max(int(max_votes), 1)
     start = torch.cumsum(counts, 0) - counts
     rank = torch.arange(tiles.numel(), device=device) - start[tiles]
-    out = torch.full((n_tiles, V), -1, dtype=torch.int32, device=device)
+    rank = torch.where(tiles < n_tiles, rank, 0).clamp_(max=V - 1)
+    out = torch.full((n_tiles + 1, V), -1, dtype=torch.int32, device=device)
     out[tiles, rank] = wins.to(torch.int32)
-    return out, counts
+    return out[:n_tiles], counts[:n_tiles]
 
 
 @torch.no_grad()
@@ -72,14 +108,13 @@ def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=
     and the head runs ONCE per tile -- mean_w(head(v_w)) = head(mean_w v_w) for a linear head, so HBM sees the
     [n_tiles, G] result once and 100x fewer head products are computed."""
     _lib.require_gpu()
-    members, _ = enumerate_windows(xtf, ytf, stride)
     dev = model.flat.device
+    mem = enumerate_windows_device(xtf, ytf, stride, dev)           # nothing below waits for the device before the result is read
     feats = tile_features.to(dev, torch.float32).contiguous()
     n_tiles, D = feats.shape
     G = model.cfg.num_outputs
-    if len(members) == 0:
+    if mem.shape[0] == 0:
         return torch.full((n_tiles, G), float("nan"), device=dev), torch.zeros(n_tiles, dtype=torch.int64, device=dev)
-    mem = torch.from_numpy(members).to(dev)
     gather = (mem[:, 0:1].expand(-1, mem.shape[1]) if literal_2d else mem).to(torch.int32).contiguous()
     # literal_2d: the reference feeds a 2-D [100, D] tensor and takes row 0 -> the prediction depends on the window's
     # first tile only, replicated over the 100 positions (SURVEY 3.5)
@@ -102,7 +137,8 @@ def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=
             win_vec[s:s + batch_windows] = model._run_head_inputs(feats, gather[s:s + batch_windows], slot=1 + i % ns)
     for st in streams:
         main.wait_stream(st)
-    lists, counts = tile_window_lists(mem, n_tiles, dev)
+    lists, counts = tile_window_lists(mem, n_tiles, dev, max_votes=(-(-10 // stride)) ** 2)      # a tile lies in <= ceil(10 / stride)^2 windows
+    lists = lists.contiguous()
     tile_vec = torch.empty(n_tiles, D, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().sq_window_vote(_lib.ptr(win_vec), W, D, _lib.ptr(lists), n_tiles, lists.shape[1],
