@@ -10,7 +10,7 @@ __global__ void add_pos_kernel(const float4* __restrict__ x, const float4* __res
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
         const float4 a = x[i], p = pos[i % nd4];
         const float4 v = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
-        X[i] = v;
+        if (X) X[i] = v;                 // (null: the bf16 stream of inference -- nobody reads the fp32 rows)
         if (Xh) Xh[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
     }
 }
@@ -26,7 +26,7 @@ __global__ void add_pos_gather_kernel(const float4* __restrict__ src, const int3
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r >= 0) a = src[(size_t)r * d4 + col];
         const float4 v = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
-        X[i] = v;
+        if (X) X[i] = v;                 // (null: the bf16 stream of inference -- nobody reads the fp32 rows)
         if (Xh) Xh[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
     }
 }

@@ -153,10 +153,11 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
     auto Wrem = [&](int64_t off) { return (size_t)(lay.total - off) * es; };
     auto Pf = [&](int64_t off) { return params + off; };
 
+    float* const x32 = (sq_vis_lean_stream(dtype) && !save) ? nullptr : w.Xin[0];      // bf16-only stream in inference: the fp32 rows have no reader
     if (x) {
-        if (int e = sq_k_add_pos(x, Pf(lay.pos), w.Xin[0], lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
+        if (int e = sq_k_add_pos(x, Pf(lay.pos), x32, lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
     } else {
-        if (int e = sq_k_add_pos_gather(gather_src, gather_idx, Pf(lay.pos), w.Xin[0], lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
+        if (int e = sq_k_add_pos_gather(gather_src, gather_idx, Pf(lay.pos), x32, lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
     }
     // Inference in bf16 mode keeps the residual stream x in bf16 only (the operand copy IS the stream): the two residual
     // products of a layer then read and write 2-byte rows instead of 4-byte rows plus a 2-byte copy, LayerNorm and the
