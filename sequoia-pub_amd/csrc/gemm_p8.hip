@@ -415,6 +415,13 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
             constexpr int i = decltype(ic)::value;
             const int mrow0 = m0_ + wr * (MF * 16) + i * 16;
             char* const sb = reinterpret_cast<char*>(slab);
+            f32x4 rb0[2], rb1[2];                    // the slide's Cs row of this lane's 8 columns: requested before the slab is written
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int m = min(mrow0 + u * 8 + e_r8, p.M - 1);
+                const float* rb = p.comb_rb + (long long)(m / p.comb_rpg) * p.comb_ldrb + e_n;
+                rb0[u] = *reinterpret_cast<const f32x4*>(rb); rb1[u] = *reinterpret_cast<const f32x4*>(rb + 4);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -468,8 +475,7 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                 if (m >= p.M || (dbg & 1)) continue;
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8);
                 const f32x4 a1 = *reinterpret_cast<const f32x4*>(slab + row * 64 + e_c8 * 8 + 4);
-                const float* rb = p.comb_rb + (long long)(m / p.comb_rpg) * p.comb_ldrb + e_n;
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rb), r1 = *reinterpret_cast<const f32x4*>(rb + 4);
+                const f32x4 r0 = rb0[u], r1 = rb1[u];
                 float w8[8] = {a0[0] + r0[0], a0[1] + r0[1], a0[2] + r0[2], a0[3] + r0[3], a1[0] + r1[0], a1[1] + r1[1], a1[2] + r1[2], a1[3] + r1[3]};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) w8[e] = sq_gelu<true>(w8[e]);
