@@ -6,7 +6,7 @@
 // Vector path: 2 x 16-byte fp32 accesses / one 16-byte bf16 access per operand.
 // EPI selects which transcendental paths are compiled in: 0 none/ReLU only, 1 + GELU activation,
 // 2 + GELU' multiply, 3 both (erff expands to >100 instructions per element, so lean kernels leave it out);
-// FAST (bf16 compute mode) takes the A&S erf
+// FAST (bf16 compute mode) takes the polynomial erf (forward) / the A&S erf sharing its exponential with the density (GELU')
 template <int EPI, bool FAST = false>
 static __device__ __forceinline__ void epi_apply(const GemmArgs& p, int z, int m, int n, float (&v)[8], int cnt, bool vec,
                                           const float* pre_res = nullptr, const float* pre_bias = nullptr, void* c_ovr = nullptr) {

@@ -99,7 +99,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
-// bf16 compute mode: erf by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 rounding of the result)
+// bf16 compute mode, GELU' (backward): erf by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 rounding of the result)
 // sharing exp(-u^2) with the Gaussian density: ~12 VALU ops per element instead of ~40 for erff + expf.  GEMM
 // epilogues with GELU / GELU' were VALU-bound on the exact forms.  fp32 (parity) mode keeps erff.
 __device__ __forceinline__ void sq_erf_exp_fast(float u, float& erf_u, float& e) {
@@ -109,12 +109,23 @@ __device__ __forceinline__ void sq_erf_exp_fast(float u, float& erf_u, float& e)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     erf_u = copysignf(1.0f - poly * e, u);
 }
+// bf16 compute mode, forward: erf as an odd polynomial on the clamped argument, erf(u) ~ z P(z^2), z = med3(u, -3, 3), degree 8 in
+// z^2 (near-minimax fit, |error| < 2.8e-5 everywhere incl. the clamp: 1 - erf(3) = 2.2e-5) -- 12 full-rate VALU operations, no
+// transcendental (v_exp / v_rcp issue at quarter rate: the A&S form above costs ~21 slots).  GELU epilogues of large products are
+// VALU time with the matrix pipes idle; the result is rounded to bf16 (2^-9 relative) right behind it.
+__device__ __forceinline__ float sq_erf_poly(float u) {
+    const float z = __builtin_amdgcn_fmed3f(u, -3.0f, 3.0f);
+    const float t = z * z;
+    float p = 4.074212256e-08f;
+    p = fmaf(p, t, -1.944823225e-06f); p = fmaf(p, t, 4.106052802e-05f); p = fmaf(p, t, -5.110368947e-04f);
+    p = fmaf(p, t, 4.235427361e-03f); p = fmaf(p, t, -2.510286123e-02f); p = fmaf(p, t, 1.110793352e-01f);
+    p = fmaf(p, t, -3.753148615e-01f); p = fmaf(p, t, 1.128268480e+00f);
+    return p * z;
+}
 template <bool FAST>
 __device__ __forceinline__ float sq_gelu(float x) {
     if constexpr (FAST) {
-        float er, e;
-        sq_erf_exp_fast(x * 0.70710678118654752440f, er, e);
-        return 0.5f * x * (1.0f + er);
+        return 0.5f * x * (1.0f + sq_erf_poly(x * 0.70710678118654752440f));
     } else {
         return gelu_erf(x);
     }
