@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
             for (int r = 0; r < 16; r += 2) {
                 const float v0 = x3_relu(s2v * acc3[r] + b2v), v1 = x3_relu(s2v * acc3[r + 1] + b2v);
                 const uint32_t h = Fmt::pack2(v0, v1);
-                const uint32_t l = Fmt::pack2(v0 - Fmt::lo_f(h), v1 - Fmt::hi_f(h));
+                const uint32_t l = Fmt::rest2(v0, v1, h);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int row = pi3 * 32 + (r & 3) + e + 8 * (r >> 2) + 4 * lh;
@@ -385,9 +385,9 @@ __global__ __launch_bounds__(256, 2) void chain_x3_kernel(const ChainX3Args p) {
                 for (int r = 0; r < 16; r += 2) {
                     const float d0 = sd * accd[i][j][r] + bd, d1 = sd * accd[i][j][r + 1] + bd;
                     const uint32_t h = Fmt::pack2(d0, d1);
-                    const uint32_t l = Fmt::pack2(d0 - Fmt::lo_f(h), d1 - Fmt::hi_f(h));
-                    acc[i][j][r] = x3_relu((s3 * acc[i][j][r] + b3) + (Fmt::lo_f(h) + Fmt::lo_f(l)));
-                    acc[i][j][r + 1] = x3_relu((s3 * acc[i][j][r + 1] + b3) + (Fmt::hi_f(h) + Fmt::hi_f(l)));
+                    const uint32_t l = Fmt::rest2(d0, d1, h);
+                    acc[i][j][r] = x3_relu((s3 * acc[i][j][r] + b3) + Fmt::sum_lo(h, l));
+                    acc[i][j][r + 1] = x3_relu((s3 * acc[i][j][r + 1] + b3) + Fmt::sum_hi(h, l));
                 }
         }
     }

@@ -294,13 +294,13 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
                         const f32x4 b = *reinterpret_cast<const f32x4*>(BS + cb), sc = *reinterpret_cast<const f32x4*>(BS + N1 + cb);
                         const u32x2 ih = lds64(a), il = lds64(a + 2048);
                         float v[4];
-                        v[0] = x3_relu((sc[0] * accy[4 * g + 0] + b[0]) + (Fmt::lo_f(ih[0]) + Fmt::lo_f(il[0])));
-                        v[1] = x3_relu((sc[1] * accy[4 * g + 1] + b[1]) + (Fmt::hi_f(ih[0]) + Fmt::hi_f(il[0])));
-                        v[2] = x3_relu((sc[2] * accy[4 * g + 2] + b[2]) + (Fmt::lo_f(ih[1]) + Fmt::lo_f(il[1])));
-                        v[3] = x3_relu((sc[3] * accy[4 * g + 3] + b[3]) + (Fmt::hi_f(ih[1]) + Fmt::hi_f(il[1])));
+                        v[0] = x3_relu((sc[0] * accy[4 * g + 0] + b[0]) + Fmt::sum_lo(ih[0], il[0]));
+                        v[1] = x3_relu((sc[1] * accy[4 * g + 1] + b[1]) + Fmt::sum_hi(ih[0], il[0]));
+                        v[2] = x3_relu((sc[2] * accy[4 * g + 2] + b[2]) + Fmt::sum_lo(ih[1], il[1]));
+                        v[3] = x3_relu((sc[3] * accy[4 * g + 3] + b[3]) + Fmt::sum_hi(ih[1], il[1]));
                         const uint32_t h0 = Fmt::pack2(v[0], v[1]), h1 = Fmt::pack2(v[2], v[3]);
-                        const uint32_t l0 = Fmt::pack2(v[0] - Fmt::lo_f(h0), v[1] - Fmt::hi_f(h0));
-                        const uint32_t l1 = Fmt::pack2(v[2] - Fmt::lo_f(h1), v[3] - Fmt::hi_f(h1));
+                        const uint32_t l0 = Fmt::rest2(v[0], v[1], h0);
+                        const uint32_t l1 = Fmt::rest2(v[2], v[3], h1);
                         st_lds64(a, u32x2{h0, h1});
                         st_lds64(a + 2048, u32x2{l0, l1});
                     }
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void chain_x3w_kernel(const ChainWArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = x3_relu(sc[e] * acc2[nt][4 * g + e] + b[e]);
                 const uint32_t h0 = Fmt::pack2(v[0], v[1]), h1 = Fmt::pack2(v[2], v[3]);
-                lo_keep[nt][g] = u32x2{Fmt::pack2(v[0] - Fmt::lo_f(h0), v[1] - Fmt::hi_f(h0)), Fmt::pack2(v[2] - Fmt::lo_f(h1), v[3] - Fmt::hi_f(h1))};
+                lo_keep[nt][g] = u32x2{Fmt::rest2(v[0], v[1], h0), Fmt::rest2(v[2], v[3], h1)};
                 st_lds64(myrow + (((nt * 4 + g) ^ sw) << 4) + 8 * lh, u32x2{h0, h1});
             }
 #pragma unroll

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NT) void conv1_pool_x3_kernel(const Conv1X3Args p) 
                     const float* px = p.f32 + ((size_t)img * 3 * S + iy) * S + ix;
                     const float x0 = px[0], x1 = px[(size_t)S * S], x2 = px[2 * (size_t)S * S];
                     hv[0] = F::pack2(x0, x1); hv[1] = F::pack2(x2, 0.f);
-                    lv[0] = F::pack2(x0 - F::lo_f(hv[0]), x1 - F::hi_f(hv[0])); lv[1] = F::pack2(x2 - F::lo_f(hv[1]), 0.f);
+                    lv[0] = F::rest2(x0, x1, hv[0]); lv[1] = F::pack2(x2 - F::lo_f(hv[1]), 0.f);
                 }
                 *reinterpret_cast<u32x2*>(s_hi + idx * 8) = hv;
                 *reinterpret_cast<u32x2*>(s_lo + idx * 8) = lv;

@@ -454,9 +454,9 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
                     for (int r = 0; r < 16; r += 2) {
                         const float d0 = sd * accd[i][j][r] + bd, d1 = sd * accd[i][j][r + 1] + bd;
                         const uint32_t h = Fmt::pack2(d0, d1);
-                        const uint32_t l = Fmt::pack2(d0 - Fmt::lo_f(h), d1 - Fmt::hi_f(h));
-                        acc[i][j][r] = x3_relu((s3 * acc[i][j][r] + b3) + (Fmt::lo_f(h) + Fmt::lo_f(l)));
-                        acc[i][j][r + 1] = x3_relu((s3 * acc[i][j][r + 1] + b3) + (Fmt::hi_f(h) + Fmt::hi_f(l)));
+                        const uint32_t l = Fmt::rest2(d0, d1, h);
+                        acc[i][j][r] = x3_relu((s3 * acc[i][j][r] + b3) + Fmt::sum_lo(h, l));
+                        acc[i][j][r + 1] = x3_relu((s3 * acc[i][j][r + 1] + b3) + Fmt::sum_hi(h, l));
                     }
             }
         }

@@ -17,6 +17,9 @@ template <> struct X3Fmt<false> {
     static __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }            // element 0 of a packed pair
     static __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }    // element 1
     static __device__ __forceinline__ float one(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+    static __device__ __forceinline__ float sum_lo(uint32_t h, uint32_t l) { return lo_f(h) + lo_f(l); }     // element 0 of hi + lo
+    static __device__ __forceinline__ float sum_hi(uint32_t h, uint32_t l) { return hi_f(h) + hi_f(l); }
+    static __device__ __forceinline__ uint32_t rest2(float a, float b, uint32_t h) { return pack2(a - lo_f(h), b - hi_f(h)); }   // the lo plane of (a, b) given their hi plane
     static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& acc) {
         union { u32x4 u; bf16x8 h; } ua, ub;
         ua.u = a; ub.u = b;
@@ -32,6 +35,22 @@ template <> struct X3Fmt<true> {
     static __device__ __forceinline__ float lo_f(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
     static __device__ __forceinline__ float hi_f(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
     static __device__ __forceinline__ float one(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+    // hi + lo and v - hi on v_fma_mix_f32 (an fp32 FMA whose operands may be either half of a packed fp16 pair): ONE instruction where
+    // v_cvt_f32_f16 + v_add / v_sub_f32 are two or three, same bits -- the conversions are exact and x * (+-1) + y rounds once, as the
+    // addition does.  hipcc does not form it on its own (round 5: 2720 v_cvt_f32_f16 in chain_x3.hip's ISA, no v_fma_mix); the
+    // epilogues of the split modes are VALU time the matrix pipes wait for.
+    static __device__ __forceinline__ float sum_lo(uint32_t h, uint32_t l) {
+        float r; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l)); return r;
+    }
+    static __device__ __forceinline__ float sum_hi(uint32_t h, uint32_t l) {
+        float r; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l)); return r;
+    }
+    static __device__ __forceinline__ uint32_t rest2(float a, float b, uint32_t h) {
+        float ra, rb;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
+        return pack2(ra, rb);
+    }
     static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& acc) {
         union { u32x4 u; f16x8 h; } ua, ub;
         ua.u = a; ub.u = b;
@@ -51,7 +70,7 @@ __device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4& hi, u32x4&
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         hi[e] = F::pack2(v[2 * e], v[2 * e + 1]);
-        lo[e] = F::pack2(v[2 * e] - F::lo_f(hi[e]), v[2 * e + 1] - F::hi_f(hi[e]));
+        lo[e] = F::rest2(v[2 * e], v[2 * e + 1], hi[e]);
     }
 }
 // hi + lo (exact in fp32: both planes are multiples of one ulp of the value they split)
@@ -60,7 +79,7 @@ __device__ __forceinline__ void x3_join8(const u32x4& hi, const u32x4& lo, float
     using F = X3Fmt<F16>;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        v[2 * e] = F::lo_f(hi[e]) + F::lo_f(lo[e]);
-        v[2 * e + 1] = F::hi_f(hi[e]) + F::hi_f(lo[e]);
+        v[2 * e] = F::sum_lo(hi[e], lo[e]);
+        v[2 * e + 1] = F::sum_hi(hi[e], lo[e]);
     }
 }
