@@ -412,12 +412,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
                 // LayerNorm over the 64-column head group this thread's 8 columns belong to: the group is 8
                 // consecutive lanes (two-pass mean / variance as nn.LayerNorm, eps 1e-5)
                 float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                sm = group8_sum(sm);
                 const float mean = sm * (1.0f / 64.0f);
                 float q = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
-                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                q = group8_sum(q);
                 const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * lng[e] + lnb[e];

@@ -365,12 +365,12 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                         u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                 if constexpr ((EPI & 4) != 0) {          // two-pass mean / variance as nn.LayerNorm, eps 1e-5 (the arithmetic of gemm.hip's epilogue)
                     float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                    sm = group8_sum(sm);
                     const float mean = sm * (1.0f / 64.0f);
                     float q = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { v[e] -= mean; q += v[e] * v[e]; }
-                    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                    q = group8_sum(q);
                     const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * lng[e] + lnb[e];
@@ -437,12 +437,12 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
                 for (int e = 0; e < 8; ++e) v[u][e] = p.alpha * t[e] + bias8[e];
                 // LayerNorm(64) as in the plain epilogue below (two-pass, eps 1e-5), then GELU: Lf
                 float sm = ((v[u][0] + v[u][1]) + (v[u][2] + v[u][3])) + ((v[u][4] + v[u][5]) + (v[u][6] + v[u][7]));
-                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                sm = group8_sum(sm);
                 const float mean = sm * (1.0f / 64.0f);
                 float q = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { v[u][e] -= mean; q += v[u][e] * v[u][e]; }
-                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                q = group8_sum(q);
                 const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[u][e] = sq_gelu<true>(v[u][e] * rstd * lng[e] + lnb[e]);

@@ -141,6 +141,20 @@ __device__ __forceinline__ float sq_gelu_grad(float x) {
     }
 }
 
+// Sum over aligned groups of 4 / 8 consecutive lanes on DPP moves (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror), every lane of
+// a group ending with the same bits as the xor-butterfly `v += __shfl_xor(v, 1); ... 2; ... 4` (only commutativity separates the two).
+// hipcc turns __shfl_xor into ds_bpermute_b32 -- an LDS round trip per step, six dependent ones per LayerNorm(64) row in the GEMM
+// epilogues (round 5: 96 of them in gemm_p8's combiner epilogue).
+__device__ __forceinline__ float sq_dpp_add(float v, int ctrl_is /* 0: xor 1, 1: xor 2, 2: the other quad of the 8-group */) {
+    const int x = __float_as_int(v);
+    const int y = ctrl_is == 0 ? __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false)
+                : ctrl_is == 1 ? __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false)
+                               : __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);
+    return v + __int_as_float(y);
+}
+__device__ __forceinline__ float group4_sum(float v) { return sq_dpp_add(sq_dpp_add(v, 0), 1); }
+__device__ __forceinline__ float group8_sum(float v) { return sq_dpp_add(sq_dpp_add(sq_dpp_add(v, 0), 1), 2); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -82,12 +82,12 @@ __global__ __launch_bounds__(256) void summary_fwd_kernel(const bf16_t* __restri
         float v[16], sm = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { v[e] = sT[row][c0 + e]; sm += v[e]; }
-        sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64);
+        sm = group4_sum(sm);
         const float mean = sm * (1.0f / 64.0f);
         float q = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { const float d = v[e] - mean; q += d * d; }
-        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+        q = group4_sum(q);
         const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
         const bool ok = b0 + row < B;
         uint32_t packed[8];
