@@ -275,27 +275,32 @@ __global__ __launch_bounds__(256, 2) void uni_attn_mfma_kernel(const bf16_t* __r
                     acc[t] = mma_bf16(*reinterpret_cast<const u32x4*>(sK + kr * 128 + (((2 * ks + lh) ^ ((kr >> 1) & 7)) << 4)), qf[ks], acc[t]);
             }
         }
-        // softmax over the keys of this lane's query
+        // softmax over the keys of this lane's query.  The scores stay unscaled: scale > 0, so the maximum commutes with it, and
+        // exp(scale (s - max)) is ONE fma into v_exp_f32 (2^x) with c = scale log2(e).  Only the last key tile holds padding keys
+        // (-inf there: 2^-inf = 0).  (Round 5: the softmax is VALU time -- ~40 k scores per workgroup -- the matrix pipes wait for.)
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             if (t < ntile) {
+                if (t == ntile - 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float sv = key < Ttok ? acc[t][r] * scale : -INFINITY;
-                    acc[t][r] = sv;
-                    mx = fmaxf(mx, sv);
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (key >= Ttok) acc[t][r] = -INFINITY;
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[t][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float cexp = scale * 1.44269504088896340736f, moff = -mx * cexp;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             if (t < ntile) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float e = __expf(acc[t][r] - mx);        // exp(-inf) = 0 for masked keys
+                    const float e = __builtin_amdgcn_exp2f(fmaf(acc[t][r], cexp, moff));
                     acc[t][r] = e;
                     sum += e;
                 }
