@@ -67,22 +67,28 @@ def bind_to_gpu_numa_node(device_index):
 
 def init_distributed():
     """Returns (rank, world, device).  Under torchrun each rank owns LOCAL_RANK's GPU and the default
-    process group is RCCL ('nccl' backend on ROCm); otherwise single GPU cuda:0."""
+    process group is RCCL ('nccl' backend on ROCm); otherwise single GPU cuda:0.  SQ_SHARE_GPU=1 (debugging aid for 1-GPU
+    boxes, the CLI twin of bench.py's SQ_BENCH_SHARE_GPU): every rank uses cuda:0 and the collectives go through gloo --
+    exercises the multi-process control flow, not RCCL."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device("cuda", local)
+    share = os.environ.get("SQ_SHARE_GPU") == "1"
+    device = torch.device("cuda", 0 if share else local)
     if torch.cuda.is_available():
+        if world > 1 and not share and torch.cuda.device_count() <= local:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local} needs {local + 1} visible GPUs, this box has {torch.cuda.device_count()} "
+                             "(one rank per GPU over RCCL; SQ_SHARE_GPU=1 runs the ranks on cuda:0 over gloo to exercise the control flow only)")
         torch.cuda.set_device(device)
         if world > 1:
             # narrows this thread's CPU mask (threads / DataLoader workers started later inherit it) and caps torch's intra-op
             # pool at 16 threads; SQ_NO_NUMA_BIND=1 opts out
-            info = bind_to_gpu_numa_node(local)
+            info = bind_to_gpu_numa_node(device.index)
             if rank == 0:
                 print(f"[sequoia-pub_amd] host NUMA binding: {info}", flush=True)
     if world > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        torch.distributed.init_process_group("nccl" if torch.cuda.is_available() and not share else "gloo")
     return rank, world, device
 
 

@@ -56,6 +56,8 @@ def main(argv=None):
     p.add_argument('--save_on', type=str, default='loss')
     p.add_argument('--stop_on', type=str, default='loss')
     p.add_argument('--compute_dtype', default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--grad_exchange', default='fp32', choices=['fp32', 'bf16'],
+                   help='wire format of the gradient all-reduce under torchrun (bf16: half the bytes, gradients rounded to bf16 on the wire)')
     args = p.parse_args(argv)
 
     seed_everything(args.seed)
@@ -119,7 +121,7 @@ def main(argv=None):
         dataloaders = {'train': train_dataloader, 'val': val_dataloader}
         if args.train:
             model = train(model, dataloaders, None, num_epochs=args.num_epochs, run=run, split=i, save_on=args.save_on,
-                          stop_on=args.stop_on, delta=0.5, save_dir=save_dir, lr=args.lr)
+                          stop_on=args.stop_on, delta=0.5, save_dir=save_dir, lr=args.lr, grad_exchange=args.grad_exchange)
         preds, real, wsis, projs = evaluate(model, test_dataloader, run=run, suff='_' + str(i), verbose=rank == 0)
         random_model = build_model(args, num_outputs, feature_dim, device).to(device)
         random_preds, _, _, _ = evaluate(random_model, test_dataloader, run=run, suff='_' + str(i) + '_rand', verbose=False)

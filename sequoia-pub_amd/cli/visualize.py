@@ -20,6 +20,7 @@ from scipy.ndimage import binary_dilation
 
 from ..patchgen import ArraySlide
 from ..spatial import sliding_window_any_model, sliding_window_method
+from .common import init_distributed
 
 BACKGROUND_THRESHOLD = .5
 
@@ -69,21 +70,36 @@ def read_tiles(slide, df, patch_size_resized, lo=0, hi=None):
     return torch.from_numpy(tiles)
 
 
-def embed_tiles(slide, df, patch_size_resized, out_size, feat_model, device, chunk=TILE_CHUNK):
+def embed_tiles(slide, df, patch_size_resized, out_size, feat_model, device, chunk=None, shard=None):
     """Feature cache [n_tiles, D] on the device: tiles go through in chunks -- read, upload, resize ON THE DEVICE
     (antialiased bilinear, uni.resize_u8) when the read size differs from the extractor's input, embed -- so only the
     features stay resident (a 40x slide with 50 000 valid tiles of 512 x 512 would otherwise need ~40 GB of host
-    uint8 plus the fp32 resize copies)."""
+    uint8 plus the fp32 resize copies).  With ``shard=(rank, world[, group])`` the chunks are dealt round-robin over the
+    ranks (chunk c to rank c % world: the same launches the one-rank run makes for those tiles) and the cache is
+    all-gathered once (SURVEY 8e "Config 5": n_tiles x D fp32), so every rank ends with the complete, identical cache."""
+    from ..spatial import _shard_info, gathered_row_of_window
     from ..uni import resize_u8
+    rank, world, group = _shard_info(shard)
+    chunk = int(chunk or TILE_CHUNK)
+    D = 2048 if hasattr(feat_model, 'conv1') else 1024
     feats = []
-    for lo in range(0, len(df), chunk):
+    starts = list(range(0, len(df), chunk))
+    for lo in starts[rank::world]:
         t = read_tiles(slide, df, patch_size_resized, lo, min(lo + chunk, len(df))).to(device)
         if patch_size_resized != out_size:
             t = resize_u8(t, out_size)
         feats.append(feat_model.extract_patches_u8(t))
-    if not feats:
-        return torch.empty(0, 2048 if hasattr(feat_model, 'conv1') else 1024, device=device)      # what the extractor would have returned for 0 tiles
-    return torch.cat(feats, 0)
+    if world == 1:
+        if not feats:
+            return torch.empty(0, D, device=device)      # what the extractor would have returned for 0 tiles
+        return torch.cat(feats, 0)
+    slots = -(-len(starts) // world)
+    local = torch.zeros(slots * chunk, D, dtype=torch.float32, device=device)
+    for i, f in enumerate(feats):
+        local[i * chunk:i * chunk + f.shape[0]] = f
+    allf = torch.empty(world * slots * chunk, D, dtype=torch.float32, device=device)
+    torch.distributed.all_gather(list(allf.chunk(world)), local, group=group)
+    return allf[gathered_row_of_window(torch.arange(len(df), device=device), chunk, world, slots)]
 
 
 def open_slide(path):
@@ -121,17 +137,22 @@ def main(argv=None):
     p.add_argument('--out_root', type=str, default='./visualizations')
     p.add_argument('--extractor_weights', type=str, default=None, help='resnet50 / UNI state dict (default: torchvision url / ./uni_ckpt/pytorch_model.bin)')
     p.add_argument('--resize_factor', type=float, default=None, help='level-0 pixels per 20x pixel (default: aperio.AppMag / 20)')
+    p.add_argument('--tile_chunk', type=int, default=TILE_CHUNK, help='tiles per read -> upload -> embed round (and the unit dealt over the ranks under torchrun)')
     p.add_argument('--compute_dtype', default='bf16', choices=['fp32', 'bf16', 'f16x3', 'bf16x3'],
                    help='f16x3 / bf16x3: the ResNet-50 extractor on split planes (fp32-class features); the aggregator then runs in fp32')
     args = p.parse_args(argv)
     assert args.feat_type in ['resnet', 'uni'] and args.model_type in ['vit', 'vis', 'he2rna']
-    device = torch.device('cuda:0')
+    # under torchrun: ONE slide over the ranks -- tile chunks for the feature cache, window batches and tile chunks for the
+    # aggregator (spatial.sliding_window_all_genes_sharded); rank 0 writes the CSV.  Alone: cuda:0 as in the reference.
+    rank, world, device = init_distributed()
+    shard = (rank, world) if world > 1 else None
     stride, patch_size = 1, 256                         # 256 px at 20x (0.5 um / px)
 
     checkpoint = args.checkpoint or f'{args.model_type}_{args.feat_type}/{args.study}/'
     gene_ids = list(read_pickle(os.path.join(checkpoint, 'test_results.pkl'))[0]['genes'])
     save_path = os.path.join(args.out_root, args.project, args.save_folder, args.wsi_file_name)
-    os.makedirs(save_path, exist_ok=True)
+    if rank == 0:
+        os.makedirs(save_path, exist_ok=True)
     if args.gene_names != 'all':
         gene_names = list(np.load(args.gene_names, allow_pickle=True)) if '.npy' in args.gene_names else args.gene_names.split(",")
     else:
@@ -158,14 +179,14 @@ def main(argv=None):
         if args.extractor_weights:
             feat_model.load_state_dict(torch.load(args.extractor_weights, map_location='cpu'))
         feat_model = feat_model.to(device).eval()
-        tile_features = embed_tiles(slide, df, patch_size_resized, 256, feat_model, device)
+        tile_features = embed_tiles(slide, df, patch_size_resized, 256, feat_model, device, chunk=args.tile_chunk, shard=shard)
     else:
         from ..uni import create_model
         feat_model = create_model("vit_large_patch16_224", img_size=224, patch_size=16, init_values=1e-5, num_classes=0,
                                   dynamic_img_size=True, compute_dtype=args.compute_dtype)
         feat_model.load_state_dict(torch.load(args.extractor_weights or "./uni_ckpt/pytorch_model.bin", map_location='cpu'), strict=True)
         feat_model = feat_model.to(device).eval()
-        tile_features = embed_tiles(slide, df, patch_size_resized, 224, feat_model, device)
+        tile_features = embed_tiles(slide, df, patch_size_resized, 224, feat_model, device, chunk=args.tile_chunk, shard=shard)
 
     # ---- fold ensemble (visualize.py:248-300)
     res_df = df.copy(deep=True)
@@ -188,7 +209,7 @@ def main(argv=None):
             model.load_state_dict(torch.load(fold_ckpt, map_location='cpu'))
         model = model.to(device).eval()
         if args.model_type == 'vis':
-            preds = sliding_window_method(df, tile_features, model, inds, stride)
+            preds = sliding_window_method(df, tile_features, model, inds, stride, shard=shard)
         else:
             preds = sliding_window_any_model(df, tile_features, model, inds, stride, args.model_type)
         for ind_gene in inds:
@@ -196,7 +217,10 @@ def main(argv=None):
     for ind_gene in inds:
         res_df[gene_ids[ind_gene]] = res_df[[gene_ids[ind_gene] + '_' + str(i) for i in folds]].mean(axis=1)
     save_name = os.path.join(save_path, 'stride-' + str(stride) + '.csv')
-    res_df.to_csv(save_name)
+    if rank == 0:
+        res_df.to_csv(save_name)
+    if world > 1:
+        torch.distributed.barrier()
     print('Done')
     return res_df, save_name
 

@@ -52,5 +52,10 @@ inline bool sq_vis_lean_stream(int dtype) {
     return dtype == SQ_BF16 && !sq_env_flag("SQ_VIS_FP32_STREAM");      // (read per call: tests flip it inside one process)
 }
 
+// What a save_for_backward forward pass stored in `workspace` (lean bf16 rows or fp32 rows): noted by sq_vis_forward_ex, checked
+// by sq_vis_backward_buckets -- a switch flipped between the two calls is an SQ_ERR_ARG, not bf16 rows re-read as fp32.
+void sq_vis_note_saved_stream(const void* workspace, bool lean);
+int sq_vis_saved_stream(const void* workspace);            // 1 lean, 0 fp32, -1 nothing noted for this workspace
+
 // dtype of the saved GELU pre-activations (U, P): the operand dtype
 inline int sq_vis_preact_dtype(int dtype) { return dtype; }

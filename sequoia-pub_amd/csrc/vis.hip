@@ -14,6 +14,8 @@
 //   H1   = GELU(Y . W1^T + b1)                          [M, D]    gemm             (:55-56)
 //   X    = H1 . W2^T + b2 + X1                          [M, D]    gemm + residual  (:57,76)
 // Head:  out = LN_D(mean_n X) . Wh^T + bh               [B, G]                     (:103-106)
+#include <mutex>
+#include <unordered_map>
 #include "vis.h"
 #include "elementwise.h"
 #include "gemm.h"
@@ -63,6 +65,23 @@ void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base,
     o->xm = (float*)a.take((size_t)B * D * 4);
     o->xn = a.take((size_t)B * D * es);
     o->bytes = sq_align_up(a.off, 256);
+}
+
+namespace {
+std::mutex g_saved_mu;
+std::unordered_map<const void*, int> g_saved_stream;       // forward workspace -> 1 lean bf16 rows / 0 fp32 rows (a handful of entries)
+}  // namespace
+
+void sq_vis_note_saved_stream(const void* workspace, bool lean) {
+    std::lock_guard<std::mutex> lk(g_saved_mu);
+    if (g_saved_stream.size() > 4096) g_saved_stream.clear();       // workspaces come and go with the caller's allocator
+    g_saved_stream[workspace] = lean ? 1 : 0;
+}
+
+int sq_vis_saved_stream(const void* workspace) {
+    std::lock_guard<std::mutex> lk(g_saved_mu);
+    auto it = g_saved_stream.find(workspace);
+    return it == g_saved_stream.end() ? -1 : it->second;
 }
 
 static int check_cfg(const sq_vis_config* c) {
@@ -153,7 +172,9 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
     auto Wrem = [&](int64_t off) { return (size_t)(lay.total - off) * es; };
     auto Pf = [&](int64_t off) { return params + off; };
 
-    float* const x32 = (sq_vis_lean_stream(dtype) && !save) ? nullptr : w.Xin[0];      // bf16-only stream in inference: the fp32 rows have no reader
+    const bool stream16 = sq_vis_lean_stream(dtype);
+    float* const x32 = stream16 ? nullptr : w.Xin[0];      // bf16-only stream (inference and training): the fp32 rows have no reader
+    if (save) sq_vis_note_saved_stream(workspace, stream16);
     if (x) {
         if (int e = sq_k_add_pos(x, Pf(lay.pos), x32, lp ? (bf16_t*)w.Xin_lp[0] : nullptr, B, N, D, st)) return e;
     } else {
@@ -166,7 +187,6 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
     // Training in bf16 mode (save_for_backward) does the same since round 5 -- BASELINE config 2 is "forward+backward bf16": the
     // layer inputs, X1 and the pre-LayerNorm(64) tensor F are stored in bf16 only (what the backward pass re-reads), fp32 master
     // weights and AdamW state stay.  SQ_VIS_FP32_STREAM=1 brings the fp32 stream back for both.
-    const bool stream16 = sq_vis_lean_stream(dtype);
     // the summary branch (token mean + three small products per layer) beside the f projection on a helper stream -- while the
     // branch is small.  At the spatial path's batches (M = 204 800 rows and more) the token mean is a 0.4 GB pass that takes more
     // from the projection than running it first costs: 437 -> 430 ms per 50 000-tile slide on ONE stream (round 5)

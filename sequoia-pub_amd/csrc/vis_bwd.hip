@@ -163,6 +163,12 @@ extern "C" int sq_vis_backward_buckets(const sq_vis_config* c, int dtype, const 
     // lean bf16 stream (vis.h): X1 and F were saved in bf16, and the gradient stream between the layers (dXin, dX1, dY, dLf) is
     // bf16 only -- no fp32 running gradient beside the operand copies
     const bool lean = sq_vis_lean_stream(dtype);
+    {
+        const int saved = sq_vis_saved_stream(fwd_workspace);
+        SQ_REQUIRE(saved < 0 || saved == (lean ? 1 : 0),
+                   "vis_backward: the forward pass saved %s rows in this workspace, the backward pass would read %s rows (SQ_VIS_FP32_STREAM changed between the two calls)",
+                   saved ? "bf16" : "fp32", lean ? "bf16" : "fp32");
+    }
     const int sdt = lean ? SQ_BF16 : SQ_F32;       // dtype of the stream tensors
     const char* wbase = lp ? (const char*)params_lp : (const char*)params;
     auto W = [&](int64_t off) { return (const void*)(wbase + (size_t)off * es); };

@@ -86,6 +86,7 @@ def _declare(lib):
         "H5Tget_class": (c.c_int, [hid_t]), "H5Tget_size": (c.c_size_t, [hid_t]), "H5Tget_sign": (c.c_int, [hid_t]),
         "H5Tclose": (c.c_int, [hid_t]), "H5Lexists": (c.c_int, [hid_t, c.c_char_p, hid_t]),
         "H5Eset_auto2": (c.c_int, [hid_t, vp, vp]),
+        "H5Pcreate": (hid_t, [hid_t]), "H5Pclose": (c.c_int, [hid_t]), "H5Pset_obj_track_times": (c.c_int, [hid_t, c.c_uint]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -217,7 +218,12 @@ class File:
         tid = _native_type(arr.dtype)
         dims = (hsize_t * max(arr.ndim, 1))(*arr.shape)
         sid = lib.H5Screate_simple(arr.ndim, dims, None)
-        did = lib.H5Dcreate2(self._fid, name.encode(), tid, sid, 0, 0, 0)
+        # h5py's default (track_times=False): no creation / modification stamps in the object header, so a file's bytes are a
+        # function of its contents -- the files of a sharded run can be compared with the one-rank run's byte for byte
+        dcpl = lib.H5Pcreate(hid_t.in_dll(lib, "H5P_CLS_DATASET_CREATE_ID_g").value)
+        if dcpl >= 0:
+            lib.H5Pset_obj_track_times(dcpl, 0)
+        did = lib.H5Dcreate2(self._fid, name.encode(), tid, sid, 0, max(dcpl, 0), 0)
         try:
             if did < 0:
                 raise OSError(f"h5lite: creating dataset '{name}' failed")
@@ -226,6 +232,8 @@ class File:
         finally:
             if did >= 0:
                 lib.H5Dclose(did)
+            if dcpl >= 0:
+                lib.H5Pclose(dcpl)
             lib.H5Sclose(sid)
         return Dataset(lib, self._fid, name)
 

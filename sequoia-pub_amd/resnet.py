@@ -145,6 +145,23 @@ class ResNet50(nn.Module):
         self._packed = (key, w, b.to(dev))
         return self._packed[1], self._packed[2]
 
+    def mark_dirty(self):
+        """Drop the packed weights and the fp32 twin's sync mark.  The caches are keyed on the tensors' autograd version counters,
+        which ``load_state_dict`` / in-place tensor ops bump but ``p.data.copy_()``, ``.data.normal_()`` and raw-pointer writes do
+        NOT: call this after such an update (load_state_dict, .to() / .cuda() and friends call it themselves)."""
+        self.__dict__["_packed"] = None
+        self.__dict__["_twin_key"] = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.mark_dirty()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.mark_dirty()
+        return out
+
     def train(self, mode=True):
         if mode and getattr(self, "_built", False):
             raise NotImplementedError("sequoia-pub_amd ResNet50 runs in eval mode only (as the reference does)")
@@ -162,7 +179,7 @@ class ResNet50(nn.Module):
             self.__dict__["_twin"] = tw                  # not a registered submodule: state_dict() keeps the reference's keys
             self.__dict__["_twin_key"] = None
         if self.__dict__.get("_twin_key") != key:        # (load_state_dict bumps every version: synced once per change, so the twin's pack cache hits)
-            tw.load_state_dict(self.state_dict(), strict=False)
+            tw.load_state_dict(self.state_dict(), strict=True)
             tw.to(self.conv1.weight.device).eval()
             self.__dict__["_twin_key"] = key
         return tw

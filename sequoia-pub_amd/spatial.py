@@ -97,29 +97,69 @@ def tile_window_lists(members, n_tiles, device, max_votes=None):
     return out[:n_tiles], counts[:n_tiles]
 
 
-@torch.no_grad()
-def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=False, batch_windows=1024):
-    """All-gene form of visualize.py:35-102 (BASELINE config 5: per-tile 20 820-gene regression): returns
-    (tile_pred f32 [n_tiles, G] with NaN for tiles no kept window covers, votes int64 [n_tiles]).
+WINDOW = 10               # tiles per window edge (visualize.py:46-52); every bound below derives from it
+HEAD_CHUNK = 4096         # tiles per head product: the fixed grid the one-rank and the sharded run share (same launches -> same bits)
 
-    Nothing of size [windows, 100, D] or [windows, G] exists: a window batch is gathered from the tile-feature cache
-    inside the model's first kernel (member indices, -1 = the zero padding of :72-75), the model stops in front of
-    its linear head, the per-tile mean / last-writer rule (:87-100) is applied to those D-vectors (sq_window_vote),
-    and the head runs ONCE per tile -- mean_w(head(v_w)) = head(mean_w v_w) for a linear head, so HBM sees the
-    [n_tiles, G] result once and 100x fewer head products are computed."""
+
+def max_votes_per_tile(stride, size=WINDOW):
+    """A tile lies in at most ceil(size / stride)^2 kept windows."""
+    return (-(-size // stride)) ** 2
+
+
+def _shard_info(shard):
+    """shard: None | (rank, world) | (rank, world, process_group).  Returns (rank, world, group)."""
+    if shard is None:
+        return 0, 1, None
+    rank, world = int(shard[0]), int(shard[1])
+    if not (0 <= rank < world):
+        raise ValueError(f"shard rank {rank} outside world {world}")
+    if world > 1 and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        raise RuntimeError("window sharding over more than one rank needs an initialised torch.distributed process group")
+    return rank, world, (shard[2] if len(shard) > 2 else None)
+
+
+def window_batch_owner(n_windows, batch_windows, world):
+    """The fixed batch grid of a slide's window list and who runs what: batch b = windows [b * batch_windows, ...) goes to rank
+    b % world as that rank's slot b // world.  Returns (n_batches, slots_per_rank)."""
+    nb = -(-n_windows // batch_windows)
+    return nb, -(-nb // world)
+
+
+@torch.no_grad()
+def sliding_window_all_genes_sharded(xtf, ytf, tile_features, model, stride, literal_2d=False, batch_windows=1024, shard=None):
+    """visualize.py:35-102 for ONE slide over `world` ranks (BASELINE config 5's multi-GPU form; SURVEY 8e "Config 5": the
+    windows of a slide are independent, visualize.py:46-52).  Every rank holds the tile-feature cache and enumerates the
+    same window list; then
+
+      1. window batches (the fixed grid of `batch_windows`) are dealt round-robin: rank r runs batches r, r + world, ...
+         through the model up to the head's input -- a [batch, D] block per batch;
+      2. ONE all-gather of those blocks (W x D fp32: 196 MB at 47 769 windows, D = 1024 -- not the 2 x 4.2 GB an all-reduce
+         of per-tile vote sums and counts over 20 820 genes would move, and no cross-rank summation whose order could differ);
+      3. tiles are dealt in chunks of HEAD_CHUNK (chunk c to rank c % world): per-tile vote over the gathered window
+         vectors in visiting order, then the linear head once per tile.
+
+    Every launch that touches a window or a tile is the launch the one-rank run makes for it (same batch, same chunk), so
+    the rows a rank returns are BIT-IDENTICAL to the one-rank result.  Returns (tile_pred f32 [n_local, G], tile_ids int64
+    [n_local] -- the df positions of those rows, ascending --, votes int64 [n_tiles] for the whole slide)."""
     _lib.require_gpu()
+    rank, world, group = _shard_info(shard)
     dev = model.flat.device
     mem = enumerate_windows_device(xtf, ytf, stride, dev)           # nothing below waits for the device before the result is read
     feats = tile_features.to(dev, torch.float32).contiguous()
     n_tiles, D = feats.shape
     G = model.cfg.num_outputs
+    chunks = range(rank, -(-n_tiles // HEAD_CHUNK), world)
+    tile_ids = torch.cat([torch.arange(c * HEAD_CHUNK, min(n_tiles, (c + 1) * HEAD_CHUNK), device=dev) for c in chunks]) if len(chunks) \
+        else torch.zeros(0, dtype=torch.int64, device=dev)
     if mem.shape[0] == 0:
-        return torch.full((n_tiles, G), float("nan"), device=dev), torch.zeros(n_tiles, dtype=torch.int64, device=dev)
+        return torch.full((tile_ids.numel(), G), float("nan"), device=dev), tile_ids, torch.zeros(n_tiles, dtype=torch.int64, device=dev)
     gather = (mem[:, 0:1].expand(-1, mem.shape[1]) if literal_2d else mem).to(torch.int32).contiguous()
     # literal_2d: the reference feeds a 2-D [100, D] tensor and takes row 0 -> the prediction depends on the window's
     # first tile only, replicated over the 100 positions (SURVEY 3.5)
     W = mem.shape[0]
-    win_vec = torch.empty(W, D, dtype=torch.float32, device=dev)
+    nb, slots = window_batch_owner(W, batch_windows, world)
+    # row of window w in the gathered buffer: [owner rank][slot][offset in batch]
+    local = torch.empty(slots * batch_windows, D, dtype=torch.float32, device=dev) if world > 1 else torch.empty(W, D, dtype=torch.float32, device=dev)
     # two batches of windows in flight on two streams (own workspaces): each forward is a chain of dependent
     # launches, a second chain fills the ramp-up / store-drain phases of the first
     main = torch.cuda.current_stream(dev)
@@ -130,32 +170,88 @@ def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=
     model._params_lp()                              # refresh the bf16 shadow on the main stream BEFORE the hand-over event:
     start = torch.cuda.Event()                      # the window streams wait on `start` only and must see the finished cast
     start.record(main)
-    for i, s in enumerate(range(0, W, batch_windows)):
+    for i, b in enumerate(range(rank, nb, world)):
+        s = b * batch_windows
         st = streams[i % ns]
         st.wait_event(start)
         with torch.cuda.stream(st):
-            win_vec[s:s + batch_windows] = model._run_head_inputs(feats, gather[s:s + batch_windows], slot=1 + i % ns)
+            o = (b // world) * batch_windows if world > 1 else s
+            n = min(batch_windows, W - s)
+            local[o:o + n] = model._run_head_inputs(feats, gather[s:s + batch_windows], slot=1 + i % ns)
     for st in streams:
         main.wait_stream(st)
-    lists, counts = tile_window_lists(mem, n_tiles, dev, max_votes=(-(-10 // stride)) ** 2)      # a tile lies in <= ceil(10 / stride)^2 windows
-    lists = lists.contiguous()
-    tile_vec = torch.empty(n_tiles, D, dtype=torch.float32, device=dev)
+    V = max_votes_per_tile(stride)
+    lists, counts = tile_window_lists(mem, n_tiles, dev, max_votes=V)
+    if os.environ.get("SQ_SPATIAL_CHECK", "0") not in ("", "0"):        # debugging aid (waits for the device): the vote table's bound
+        assert int(counts.max()) <= V, f"a tile lies in {int(counts.max())} windows, the vote table holds {V}"
+    if world > 1:
+        win_vec = torch.empty(world * slots * batch_windows, D, dtype=torch.float32, device=dev)
+        torch.distributed.all_gather(list(win_vec.chunk(world)), local, group=group)
+        lists = gathered_row_of_window(lists, batch_windows, world, slots).to(torch.int32)
+    else:
+        win_vec = local
+    if tile_ids.numel() == 0:
+        return torch.empty(0, G, dtype=torch.float32, device=dev), tile_ids, counts
+    lists = lists[tile_ids].contiguous() if world > 1 else lists.contiguous()
+    tile_vec = torch.empty(lists.shape[0], D, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().sq_window_vote(_lib.ptr(win_vec), W, D, _lib.ptr(lists), n_tiles, lists.shape[1],
-                                             1 if stride == 10 else 0, float("nan"), _lib.ptr(tile_vec), _lib.stream_ptr(dev)))
-    return model.apply_head(tile_vec), counts
+        _lib.check(_lib.lib().sq_window_vote(_lib.ptr(win_vec), win_vec.shape[0], D, _lib.ptr(lists), lists.shape[0], lists.shape[1],
+                                             1 if stride == WINDOW else 0, float("nan"), _lib.ptr(tile_vec), _lib.stream_ptr(dev)))
+    return model.apply_head(tile_vec, chunk=HEAD_CHUNK), tile_ids, counts
 
 
 @torch.no_grad()
-def sliding_window_method(df, tile_features, model, inds_gene_of_interest, stride, literal_2d=False, batch_windows=512):
+def sliding_window_all_genes(xtf, ytf, tile_features, model, stride, literal_2d=False, batch_windows=1024):
+    """All-gene form of visualize.py:35-102 (BASELINE config 5: per-tile 20 820-gene regression): returns
+    (tile_pred f32 [n_tiles, G] with NaN for tiles no kept window covers, votes int64 [n_tiles]).
+
+    Nothing of size [windows, 100, D] or [windows, G] exists: a window batch is gathered from the tile-feature cache
+    inside the model's first kernel (member indices, -1 = the zero padding of :72-75), the model stops in front of
+    its linear head, the per-tile mean / last-writer rule (:87-100) is applied to those D-vectors (sq_window_vote),
+    and the head runs ONCE per tile -- mean_w(head(v_w)) = head(mean_w v_w) for a linear head, so HBM sees the
+    [n_tiles, G] result once and 100x fewer head products are computed.  (The one-rank case of
+    sliding_window_all_genes_sharded.)"""
+    out, _, counts = sliding_window_all_genes_sharded(xtf, ytf, tile_features, model, stride, literal_2d=literal_2d,
+                                                     batch_windows=batch_windows, shard=None)
+    return out, counts
+
+
+def gathered_row_of_window(w, batch_windows, world, slots):
+    """Row of window `w` (tensor or int, -1 = padding stays -1) in the all-gathered buffer [world][slots][batch_windows]."""
+    b = w // batch_windows                                          # (-1 stays negative through the floor division)
+    row = (b % world) * (slots * batch_windows) + (b // world) * batch_windows + w % batch_windows
+    return torch.where(w >= 0, row, w) if torch.is_tensor(w) else (row if w >= 0 else w)
+
+
+@torch.no_grad()
+def sliding_window_method(df, tile_features, model, inds_gene_of_interest, stride, literal_2d=False, batch_windows=512, shard=None):
     """visualize.py:35-102.  df: DataFrame with integer columns xcoord_tf / ycoord_tf (tile grid); tile_features:
     [n_tiles, D] tensor (row i = features of df.iloc[i], i.e. the feature cache); model: ViS on the GPU.
     Returns {gene_index: {tile_index: prediction}} exactly like the reference (stride 10: last writer wins;
-    stride < 10: mean over the windows containing the tile)."""
+    stride < 10: mean over the windows containing the tile).  With ``shard=(rank, world[, group])`` the slide's windows and
+    tiles are dealt over the ranks (sliding_window_all_genes_sharded); the requested gene columns of every rank's tiles are
+    all-gathered, so every rank returns the same, complete dictionary -- bit-identical to the one-rank call."""
     genes = list(inds_gene_of_interest)
-    out, counts = sliding_window_all_genes(df['xcoord_tf'].values, df['ycoord_tf'].values, tile_features, model, stride,
-                                           literal_2d=literal_2d, batch_windows=batch_windows)
-    sel = out[:, torch.as_tensor(genes, device=out.device)].cpu().numpy() if genes else np.zeros((out.shape[0], 0), np.float32)
+    rank, world, group = _shard_info(shard)
+    out, tile_ids, counts = sliding_window_all_genes_sharded(df['xcoord_tf'].values, df['ycoord_tf'].values, tile_features, model, stride,
+                                                            literal_2d=literal_2d, batch_windows=batch_windows, shard=shard)
+    n_tiles = counts.numel()
+    sel_local = out[:, torch.as_tensor(genes, device=out.device)] if genes else out[:, :0]
+    if world > 1:
+        # equal-sized blocks for the collective: every rank owns at most ceil(chunks / world) head chunks
+        per = -(-(-(-n_tiles // HEAD_CHUNK)) // world) * HEAD_CHUNK
+        blk = torch.full((per, len(genes) + 1), float("nan"), dtype=torch.float32, device=out.device)
+        blk[:tile_ids.numel(), :len(genes)] = sel_local
+        blk[:tile_ids.numel(), len(genes)] = tile_ids.to(torch.float32)           # (tile ids < 2^24: exact in fp32)
+        blk[tile_ids.numel():, len(genes)] = -1
+        allb = torch.empty(world * per, len(genes) + 1, dtype=torch.float32, device=out.device)
+        torch.distributed.all_gather(list(allb.chunk(world)), blk, group=group)
+        ids = allb[:, len(genes)].to(torch.int64)
+        sel_t = torch.full((n_tiles, len(genes)), float("nan"), dtype=torch.float32, device=out.device)
+        sel_t[ids[ids >= 0]] = allb[ids >= 0, :len(genes)]
+        sel = sel_t.cpu().numpy()
+    else:
+        sel = sel_local.cpu().numpy() if genes else np.zeros((n_tiles, 0), np.float32)
     cnt = counts.cpu().numpy()
     index = list(df.index)
     preds = {g: {} for g in genes}

@@ -121,17 +121,22 @@ class FusedTrainStep:
 
     Equivalent to vit.py:163-180 with ``torch.optim.AdamW(lr, amsgrad=False, weight_decay=0.)``
     (main.py:180-183).  With world_size > 1 the per-rank gradient of the local batch is summed over
-    ranks and the loss normalised by the GLOBAL element count, so the update equals the
-    single-device update on the concatenated batch.
+    ranks and the loss normalised by the GLOBAL element count.  With the default fp32 wire format the update
+    equals the single-device update on the concatenated batch up to the summation order (1e-5 of a tensor's
+    maximum, tests/test_gpu_ddp.py); with ``grad_exchange='bf16'`` (opt-in: BASELINE config 4's "bf16"
+    exchange, half the bytes) every bucket is rounded to bf16 once before the sum and the ranks' partial sums
+    are rounded again on the way round the ring -- the exchanged gradient then agrees with the single-device
+    one to ~2^-8 of each tensor's maximum (world_size - 1 roundings at worst), all ranks still bit-identical.
     """
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=1, metrics=False,
                  grad_exchange=None):
-        """grad_exchange: 'bf16' | 'fp32' -- the wire format of the gradient all-reduce (world_size > 1).  Default: the
-        environment's SQ_DDP_GRAD_EXCHANGE, else 'bf16' for a model in the bf16 compute mode (BASELINE config 4: "RCCL grad
-        all-reduce over xGMI, bf16": half the ring traffic) and 'fp32' for the exact fp32 mode.  bf16: every bucket is cast to
-        bf16 behind its completion event, summed over the ranks in bf16, cast back into the fp32 flat gradient AdamW reads;
-        master weights, moments and the local accumulation stay fp32."""
+        """grad_exchange: 'fp32' | 'bf16' -- the wire format of the gradient all-reduce (world_size > 1).  Default 'fp32'
+        (multi-rank numerics == single-rank numerics); 'bf16' is opt-in (BASELINE config 4: "RCCL grad all-reduce over xGMI,
+        bf16": half the ring traffic; bench.py's train_kfold workload and ``cli.main --grad_exchange bf16`` ask for it): every
+        bucket is cast to bf16 behind its completion event, summed over the ranks in bf16, cast back into the fp32 flat
+        gradient AdamW reads; master weights, moments and the local accumulation stay fp32.  Held to the fp32 exchange over 12
+        steps on 8 ranks by tests/test_gpu_ddp.py."""
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.world = world_size
@@ -149,7 +154,7 @@ class FusedTrainStep:
         self.adamw_buckets = os.environ.get("SQ_ADAMW_BUCKETS", "0") == "1" and model._C_BWD == "sq_vis_backward"
         self.overlap = self.overlap or self.adamw_buckets
         if grad_exchange is None:
-            grad_exchange = os.environ.get("SQ_DDP_GRAD_EXCHANGE") or ("bf16" if model.compute_dtype == _lib.SQ_BF16 else "fp32")
+            grad_exchange = "fp32"
         if grad_exchange not in ("bf16", "fp32"):
             raise ValueError(f"grad_exchange {grad_exchange!r}: 'bf16' or 'fp32'")
         self.grad_exchange = grad_exchange
@@ -217,15 +222,14 @@ class FusedTrainStep:
                 self.comm_stream.wait_event(ev)
                 if not empty and sample and i == 0:
                     tc0.record(self.comm_stream)
-                if reduce_ or self._wire is not None:
+                if reduce_:                   # (no process group: nothing is exchanged and nothing is rounded)
                     with torch.cuda.stream(self.comm_stream):
                         if self._wire is None:
                             dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
                         else:                 # bf16 on the wire: pack -> sum over ranks in bf16 -> unpack into the fp32 gradient
                             cs = _lib.stream_ptr(dev)                   # inside the block: the communication stream
                             _lib.check(_lib.lib().sq_cast_f32_to_bf16(_lib.ptr(gflat[lo:hi]), _lib.ptr(self._wire[lo:hi]), hi - lo, cs))
-                            if reduce_:
-                                dist.all_reduce(self._wire[lo:hi], op=dist.ReduceOp.SUM)
+                            dist.all_reduce(self._wire[lo:hi], op=dist.ReduceOp.SUM)
                             _lib.check(_lib.lib().sq_cast_bf16_to_f32(_lib.ptr(self._wire[lo:hi]), _lib.ptr(gflat[lo:hi]), hi - lo, cs))
                 if not self.adamw_buckets:
                     continue
@@ -378,14 +382,14 @@ def _paired_batches(loader, device):
 def train(model, dataloaders, optimizer=None, accelerator=None,
           num_epochs=200, save_dir='exp/', patience=20,
           run=None, verbose=True, phases=['train', 'val'], split=None,
-          save_on='loss', stop_on='loss', delta=0.5, lr=1e-3):
+          save_on='loss', stop_on='loss', delta=0.5, lr=1e-3, grad_exchange=None):
     """Same contract as vit.py:117-243.  ``optimizer`` may be a torch optimizer over
     ``model.parameters()`` (used through autograd) or None (fused AdamW step, the fast path).
 
     Under torch.distributed every rank feeds its own shard of the training batches; the gradient of the step is
     the gradient of the MSE over the union of the ranks' batches (summed over ranks, normalised by the global
     element count), in both the fused and the torch-optimizer path.  A rank whose batch collated to nothing still
-    takes part in the exchange with a zero gradient."""
+    takes part in the exchange with a zero gradient.  ``grad_exchange`` ('fp32' default | 'bf16'): FusedTrainStep's wire format."""
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     if save_dir is not None and not os.path.exists(save_dir) and rank == 0:
@@ -394,7 +398,7 @@ def train(model, dataloaders, optimizer=None, accelerator=None,
     # but no checkpoint file is written (benchmarks)
     save_path = None if save_dir is None else os.path.join(save_dir, f'model_best_{split}.pt' if split else 'model_best.pt')
 
-    fused = FusedTrainStep(model, lr=lr, world_size=world, metrics=True) if optimizer is None else None
+    fused = FusedTrainStep(model, lr=lr, world_size=world, metrics=True, grad_exchange=grad_exchange) if optimizer is None else None
     dev = model.flat.device
     policy = CheckpointPolicy(save_on, stop_on, patience, delta)
     observing = [ph for ph in phases if ph == 'val'] or (list(phases) if len(phases) == 1 else [])

@@ -316,8 +316,11 @@ class ViS(nn.Module, PyTorchModelHubMixin):
                                                     _lib.ptr(ws), ws.numel(), _lib.stream_ptr(cache.device)))
         return out
 
-    def apply_head(self, head_in):
-        """linear_head[1] of the reference (tformer_lin.py:91-94,106) on already normalised inputs f32 [R, D] -> f32 [R, G]."""
+    def apply_head(self, head_in, chunk=32768):
+        """linear_head[1] of the reference (tformer_lin.py:91-94,106) on already normalised inputs f32 [R, D] -> f32 [R, G],
+        `chunk` rows per product (callers that shard rows over ranks pass the grid they share with the one-rank run)."""
+        if not 0 < chunk <= 32768:
+            raise ValueError("apply_head: chunk must be in 1..32768 (operand extents stay below the 2 GiB buffer-descriptor limit)")
         R, D = head_in.shape
         G = self.cfg.num_outputs
         lay, dev = self.layout, head_in.device
@@ -331,8 +334,8 @@ class ViS(nn.Module, PyTorchModelHubMixin):
             w_ptr = ctypes.c_void_p(self.flat.data_ptr() + 4 * lay.head_w)
         b_ptr = ctypes.c_void_p(self.flat.data_ptr() + 4 * lay.head_b)
         with torch.cuda.device(dev):
-            for r0 in range(0, R, 32768):                  # operand extents stay below the 2 GiB buffer-descriptor limit
-                r1 = min(R, r0 + 32768)
+            for r0 in range(0, R, chunk):
+                r1 = min(R, r0 + chunk)
                 _lib.check(_lib.lib().sq_linear(self.compute_dtype, _lib.ptr(a[r0:r1]), D, w_ptr, D, b_ptr, None, 0, 0, 0,
                                                 _lib.ptr(out[r0:r1]), _lib.SQ_F32, G, r1 - r0, G, D, None, 0, _lib.stream_ptr(dev)))
         return out

@@ -22,10 +22,59 @@ def model():
     return ViS(**CFG, device="cuda:0", compute_dtype="fp32").to("cuda:0")
 
 
+def trajectory(rank, world, ok_path, steps=12):
+    """`world` ranks (8 in the test), two slides each, `steps` optimizer steps: the bf16 wire format against the fp32 wire format
+    and against ONE rank on the concatenated batch -- the full-batch loss after every step and the parameters at the end.  Rounding
+    on the wire grows with the ring length (world - 1 partial sums), which two ranks for two steps do not show."""
+    g = torch.Generator().manual_seed(11)
+    n = 2 * world
+    x = torch.randn(n, 100, 128, generator=g).cuda()
+    y = (torch.rand(n, 50, generator=g) * 8).cuda()
+    rows = slice(2 * rank, 2 * rank + 2)
+
+    def run(wire, ranks):
+        m = model()
+        st = sq_train.FusedTrainStep(m, lr=1e-3, world_size=ranks, grad_exchange=wire)
+        losses = []
+        for _ in range(steps):
+            if ranks > 1:
+                st.step(x[rows], y[rows], n_global=n * 50)
+            else:
+                st.step(x, y)
+            with torch.no_grad():
+                losses.append(float(((m(x) - y) ** 2).mean()))
+        torch.cuda.synchronize()
+        return losses, m.flat.detach().clone()
+
+    lb, pb = run("bf16", world)
+    lf, pf = run("fp32", world)
+    for p in (pb, pf):                                   # whatever the wire format, every rank must hold the same parameters
+        allp = [torch.empty_like(p) for _ in range(world)]
+        dist.all_gather(allp, p)
+        assert all(torch.equal(a, allp[0]) for a in allp), "ranks diverged"
+    if rank == 0:
+        l1, p1 = run("fp32", 1)
+        gap_b = max(abs(a - b) / b for a, b in zip(lb, l1))
+        gap_f = max(abs(a - b) / b for a, b in zip(lf, l1))
+        db, df = (pb - p1).abs(), (pf - p1).abs()
+        print(f"ddp{world} trajectory over {steps} steps: loss {l1[0]:.4f} -> {l1[-1]:.4f}; worst relative loss gap to the one-rank run: "
+              f"bf16 wire {gap_b:.2e}, fp32 wire {gap_f:.2e}; parameter diff max/mean: bf16 {float(db.max()):.2e}/{float(db.mean()):.2e}, "
+              f"fp32 {float(df.max()):.2e}/{float(df.mean()):.2e}")
+        assert l1[-1] < l1[0]                              # it trains
+        assert gap_f < 1e-4 and gap_b < 5e-3
+        # AdamW at lr 1e-3: a parameter moves <= lr per step; a gradient whose sign the wire rounding flips costs <= 2 lr per step
+        assert float(db.max()) <= 2e-3 * steps and float(db.mean()) < 2e-4 and float(df.mean()) < 2e-5
+        open(ok_path, "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
+    if len(sys.argv) > 2 and sys.argv[2] == "trajectory":
+        return trajectory(rank, world, sys.argv[1])
     g = torch.Generator().manual_seed(3)
     x = torch.randn(6, 100, 128, generator=g).cuda()
     y = (torch.rand(6, 50, generator=g) * 8).cuda()

@@ -75,6 +75,31 @@ def test_linear_bf16_mfma(M, N, K):
     assert rel_err(out16, torch.relu(ref)) < 5e-3
 
 
+def test_fast_gelu_epilogue_decays_for_large_negative_pre_activations():
+    """bf16 mode's GELU epilogue (sq_common.h sq_gelu<true>: erf as a polynomial on an argument clamped to +-3) for pre-activations
+    in [-30, -4.3], far left of the clamp: the exact value lies in (-4.7e-5, 0]; the clamped polynomial alone would return
+    -1.1e-5 |x|.  fp32 outputs, so nothing hides behind a bf16 rounding."""
+    _lib.require_gpu()
+    N, K = 256, 64
+    pre = -(4.3 + (30 - 4.3) * torch.arange(N) / (N - 1))
+    pre = pre.to(torch.bfloat16).float()                      # exact in bf16: the product below reproduces it exactly
+    A = torch.zeros(128, K)
+    A[:, 0] = 1.0
+    W = torch.zeros(N, K)
+    W[:, 0] = pre
+    out = run_linear(_lib.SQ_BF16, A, W, None, None, 1)
+    ref = torch.nn.functional.gelu(pre.double()).float().expand(128, N)
+    err = float((out - ref).abs().max())
+    print(f"fast GELU, x in [-30, -4.3]: max abs error {err:.2e}, most negative output {float(out.min()):.2e}")
+    assert err < 6e-5 and float(out.min()) > -6e-5
+    # and around the clamp / in the bulk the polynomial is within its stated bound
+    pre2 = torch.linspace(-4.2, 4.2, N).to(torch.bfloat16).float()
+    W[:, 0] = pre2
+    out2 = run_linear(_lib.SQ_BF16, A, W, None, None, 1)
+    ref2 = torch.nn.functional.gelu(pre2.double()).float().expand(128, N)
+    assert float((out2 - ref2).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (1024, 1024, 6400), (64, 128, 20824), (200, 520, 4104)])
 @pytest.mark.parametrize("dtype", [_lib.SQ_F32, _lib.SQ_BF16])
 def test_split_k_path(M, N, K, dtype):

@@ -382,3 +382,30 @@ def test_adamw_per_bucket_is_bit_identical_to_one_pass(monkeypatch):
     l1, p1, s1 = run()
     assert not s0.adamw_buckets and s1.adamw_buckets and s1.overlap
     assert l0 == l1 and torch.equal(p0, p1)
+
+
+def test_stream_switch_flipped_between_forward_and_backward_is_an_error_not_garbage(monkeypatch):
+    """bf16 mode saves the residual stream in bf16 (lean) or fp32 (SQ_VIS_FP32_STREAM=1) and the backward pass re-reads it: the
+    forward pass notes which, and a backward pass that would read the other kind fails loudly."""
+    _lib.require_gpu()
+    cfg = dict(num_outputs=40, input_dim=128, depth=2, nheads=2, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    torch.manual_seed(3)
+    m = ViS(**cfg, device="cuda:0", compute_dtype="bf16").to("cuda:0")
+    x = torch.randn(4, 100, 128, device="cuda")
+    y = torch.rand(4, 40, device="cuda") * 8
+    monkeypatch.delenv("SQ_VIS_FP32_STREAM", raising=False)
+    pred = m(x)
+    _, g = sq_train.mse_loss_grad(m, pred.detach(), y)
+    monkeypatch.setenv("SQ_VIS_FP32_STREAM", "1")
+    with pytest.raises(_lib.SequoiaHipError, match="SQ_VIS_FP32_STREAM"):
+        pred.backward(g)
+    # both passes under one setting: fine either way, and the two settings agree to bf16 accuracy
+    grads = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SQ_VIS_FP32_STREAM", flag)
+        m.flat.grad = None
+        pred = m(x)
+        _, g = sq_train.mse_loss_grad(m, pred.detach(), y)
+        pred.backward(g)
+        grads[flag] = m.flat.grad.detach().clone()
+    assert rel_err(grads["0"].cpu().numpy(), grads["1"].cpu().numpy()) < 3e-2

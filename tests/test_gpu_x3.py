@@ -118,6 +118,73 @@ def test_linear_x3_matches_three_term_formula_and_true_product(M, N, K, act, use
     assert rel_err(out, true) < TOL[fmt][0] + TOL[fmt][1]
 
 
+def _rel_per_element(out, exact):
+    return float(((out - exact).abs() / exact.abs().clamp_min(1e-300)).max())
+
+
+def test_f16x3_subnormal_planes_reach_the_matrix_pipe_bit_for_bit(block_shape):
+    """Does gfx950's v_mfma_f32_32x32x16_f16 honour fp16 SUBNORMAL inputs?  csrc/x3_fmt.h's error statement ("absolute error
+    <= 2^-25 below 2^-3") rests on it: below 2^-3 the lo plane of a value is an fp16 subnormal (|lo| < 2^-14).  Rows whose
+    results are known bit for bit: a = 2^-10 + 2^-22 splits into hi = 2^-10 and lo = 2^-22 (a subnormal: 4 x 2^-24); against a
+    weight of 2^-11 (a stored plane of exactly 1) the result must be a 2^-11 -- a flushed lo plane would return 2^-21 alone.
+    Likewise a SUBNORMAL HI plane (a = 2^-20), the smallest subnormal (2^-24), a negative subnormal lo plane, and a weight
+    whose lo plane is subnormal."""
+    _lib.require_gpu()
+    K, N, M = 64, 64, 128
+    u = 2.0 ** -11                                        # run_x3 stores fp16 weight rows times 2^11 and undoes it in the epilogue
+    A = torch.zeros(M, K, dtype=torch.float64)
+    W = torch.zeros(N, K, dtype=torch.float64)
+    A[0, 0] = 2.0 ** -10 + 2.0 ** -22                      # hi 2^-10, lo 2^-22 (subnormal)
+    A[1, 0] = 2.0 ** -20                                   # hi subnormal, lo 0
+    A[2, 0] = 2.0 ** -24                                   # the smallest fp16 subnormal
+    A[3, 0] = 2.0 ** -3 - 2.0 ** -15                       # just under 2^-3: hi rounds to 2^-3, lo = -2^-15 (subnormal, negative)
+    A[4, 0], A[4, 1] = 2.0 ** -12 + 2.0 ** -24, 2.0 ** -13 + 2.0 ** -24      # two terms, both lo planes the smallest subnormal
+    W[:, 0] = u                                            # stored plane exactly 1: hi 1, lo 0
+    W[:, 1] = 2 * u
+    W[1, 0] = (1.0 + 2.0 ** -20) * u                       # a weight whose lo plane is subnormal: hi 1, lo 2^-20
+    Af, Wf = A.float(), W.float()
+    exact = three_term(Af, Wf, 1)                          # fp64 value of a_hi.w_hi + a_hi.w_lo + a_lo.w_hi on the planes as stored
+    ah, al = split(Af, 1)
+    assert float(al[0, 0]) == 2.0 ** -22 and float(ah[1, 0]) == 2.0 ** -20 and float(al[4, 1]) == 2.0 ** -24      # the planes ARE subnormal
+    assert float(al[3, 0]) == -2.0 ** -15 and float(split(Wf / u, 1)[1][1, 0]) == 2.0 ** -20
+    out = run_x3(Af, Wf, None, None, 0, f32_out=True, fmt=1)
+    # every product here is exact in fp32 and every partial sum fits 24 bits: the result is known bit for bit
+    assert float(out[0, 0]) == (2.0 ** -10 + 2.0 ** -22) * u, f"lo plane flushed? got {float(out[0, 0]):.10e}, the hi plane alone gives {2.0 ** -21:.10e}"
+    assert float(out[1, 0]) == 2.0 ** -20 * u and float(out[2, 5]) == 2.0 ** -24 * u, "subnormal hi plane flushed"
+    assert float(out[4, 7]) == ((2.0 ** -12 + 2.0 ** -24) + 2 * (2.0 ** -13 + 2.0 ** -24)) * u
+    assert float(out[0, 1]) == (2.0 ** -10 + 2.0 ** -22 + 2.0 ** -30) * u and float(out[3, 0]) == (2.0 ** -3 - 2.0 ** -15) * u
+    assert torch.equal(out.float(), exact.float()), _rel_per_element(out, exact.clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("lo_exp,hi_exp,wlo,whi,K", [(-14, -6, -6, 0, 256), (-14, -6, -6, 0, 64), (4, 15, -8, -3, 64), (-24, -14, -3, 0, 128)])
+def test_f16x3_small_and_large_operands_per_element(lo_exp, hi_exp, wlo, whi, K, block_shape):
+    """sq_linear_x3 on fp16 planes against the fp64 three-term formula PER ELEMENT (relative, not max-norm) where the O(1)
+    operands of the other tests say nothing: activations in [2^-14, 2^-6) -- every lo plane entirely subnormal --, in
+    [2^-24, 2^-14) -- the HI plane subnormal too --, and in [2^4, 2^15) near the top of fp16's range.  Operands are positive, so
+    no cancellation hides a lost term: a flushed lo plane costs ~2^-12 relative (1.3e-4 ... 2.3e-4 on these draws, a flushed hi
+    plane everything); the bound is fp32 accumulation.  Against the TRUE product: x3_fmt.h's statement -- 2^-22 relative per
+    operand, or 2^-25 absolute per activation below 2^-3."""
+    _lib.require_gpu()
+    M, N = 300, 128
+    g = torch.Generator().manual_seed(K + hi_exp * 7 + lo_exp)
+    A = 2.0 ** (lo_exp + (hi_exp - lo_exp) * torch.rand(M, K, generator=g, dtype=torch.float64))
+    W = 2.0 ** (wlo + (whi - wlo) * torch.rand(N, K, generator=g, dtype=torch.float64))
+    A, W = A.float(), W.float()
+    ah, al = split(A, 1)
+    if hi_exp <= -6:
+        assert float(al.float().abs().max()) < 2.0 ** -14, "the lo plane must be subnormal (or zero) throughout"
+    exact = three_term(A, W, 1)
+    true = A.double() @ W.double().T
+    out = run_x3(A, W, None, None, 0, f32_out=True, fmt=1)
+    assert torch.isfinite(out).all()
+    e_exact = _rel_per_element(out, exact)
+    slack = (out - true).abs() - (4e-6 * true + (2.0 ** -25 * W.double().sum(1))[None, :] * (1.0 if hi_exp <= -3 else 0.0))
+    print(f"f16x3 operands in [2^{lo_exp}, 2^{hi_exp}), K={K}: worst per-element rel err vs the three-term formula {e_exact:.2e}, "
+          f"vs the true product {_rel_per_element(out, true):.2e}")
+    assert e_exact < 2e-6 * max(1.0, (K / 64) ** 0.5), e_exact
+    assert float(slack.max()) <= 0, float(slack.max())
+
+
 @pytest.mark.parametrize("fmt", [0, 1])
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,H", [(64, 64, 3, 1, 1, 14), (128, 128, 3, 2, 1, 28), (256, 512, 1, 2, 0, 14), (32, 72, 3, 1, 1, 9)])
 def test_conv_x3_implicit_gemm(Cin, Cout, k, stride, pad, H, fmt, block_shape):

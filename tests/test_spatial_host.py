@@ -34,3 +34,53 @@ def test_device_enumeration_rejects_duplicates_and_handles_empty_grids():
         enumerate_windows_device(np.array([0, 1, 1]), np.array([0, 2, 2]), 1, "cpu")
     assert enumerate_windows_device(np.array([0]), np.array([0]), 1, "cpu").shape == (0, 100)
     assert enumerate_windows_device(np.arange(5), np.arange(5), 1, "cpu").shape == (0, 100)      # windows exist, none holds > 50 tiles
+
+
+def _gather_worker(rank, world, port, W, B):
+    """One of `world` gloo ranks: fills its window-batch slots (batch b -> rank b % world, slot b // world) with the window ids,
+    all-gathers exactly as spatial.sliding_window_all_genes_sharded does, and checks that the remapped vote lists address every
+    window's own row."""
+    import os
+    import torch.distributed as dist
+    from sequoia_pub_amd.spatial import gathered_row_of_window, window_batch_owner
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nb, slots = window_batch_owner(W, B, world)
+    local = torch.full((slots * B, 3), float("nan"))
+    for b in range(rank, nb, world):
+        s, n = b * B, min(B, W - b * B)
+        o = (b // world) * B
+        local[o:o + n] = torch.arange(s, s + n, dtype=torch.float32).unsqueeze(1).expand(n, 3)
+    allv = torch.empty(world * slots * B, 3)
+    dist.all_gather(list(allv.chunk(world)), local)
+    w = torch.cat([torch.arange(W), torch.tensor([-1, -1])])
+    rows = gathered_row_of_window(w, B, world, slots)
+    assert bool((rows[W:] == -1).all()) and rows[:W].unique().numel() == W
+    assert torch.equal(allv[rows[:W], 0], torch.arange(W, dtype=torch.float32))
+    assert gathered_row_of_window(W - 1, B, world, slots) == int(rows[W - 1]) and gathered_row_of_window(-1, B, world, slots) == -1
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,B", [(47, 8), (16, 8), (5, 8), (33, 4)])
+def test_window_batches_dealt_over_two_gloo_ranks_gather_back_to_every_windows_row(W, B):
+    """The N > 1 bookkeeping of BASELINE config 5's window sharding on world_size 2 over gloo (CPU): ragged last batch, a rank
+    with an empty last slot (16 / 8 -> one batch each; 5 / 8 -> rank 1 owns nothing)."""
+    import os
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() + W * 7 + B) % 2000
+    mp.spawn(_gather_worker, args=(2, port, W, B), nprocs=2, join=True)
+
+
+def test_one_rank_gather_map_is_the_identity_and_shard_arguments_are_checked():
+    from sequoia_pub_amd.spatial import _shard_info, gathered_row_of_window, max_votes_per_tile, window_batch_owner
+    nb, slots = window_batch_owner(47769, 1024, 1)
+    assert (nb, slots) == (47, 47)
+    w = torch.arange(47769)
+    assert torch.equal(gathered_row_of_window(w, 1024, 1, slots), w)
+    assert window_batch_owner(47769, 1024, 8) == (47, 6)
+    assert [max_votes_per_tile(s) for s in (1, 3, 5, 10)] == [100, 16, 4, 1]
+    assert _shard_info(None) == (0, 1, None)
+    with pytest.raises(ValueError):
+        _shard_info((2, 2))
+    with pytest.raises(RuntimeError):
+        _shard_info((0, 2))                        # no process group in this process
