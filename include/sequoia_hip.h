@@ -42,9 +42,14 @@ int sq_device_ok(void);
 /* HIP-event timing of the library's own launches (bench.py roofline leg; no reference
  * counterpart).  sq_prof_enable(1) makes every instrumented launch record two events on
  * its stream; sq_prof_report writes a JSON array of {name,count,total_ms,flops,bytes}
- * (flops/bytes = algorithmic work per launch) into buf and clears the records. */
+ * (flops/bytes = algorithmic work per launch) into buf and clears the records.
+ * sq_prof_enable(2) additionally brackets every instrumented launch with marker launches whose grid size
+ * carries the launch's class number ((id + 2) blocks of 64 threads in front, one block behind), so that a
+ * dispatch-ordered counter trace (rocprofv3 --kernel-trace --pmc) can be attributed to classes without
+ * knowing kernel symbols; sq_prof_marker_names writes the JSON array id -> class name. */
 int sq_prof_enable(int on);
 int sq_prof_report(char* buf, size_t cap);
+int sq_prof_marker_names(char* buf, size_t cap);
 
 /* ------------------------------------------------------------------------------
  * ViS aggregator  (src/tformer_lin.py:80-106 ViS; :64-77 SummaryTransformer;

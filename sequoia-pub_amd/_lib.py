@@ -141,6 +141,8 @@ def _declare(lib):
     lib.sq_prof_enable.argtypes = [i32]
     lib.sq_prof_report.restype = i32
     lib.sq_prof_report.argtypes = [ctypes.c_char_p, sz]
+    lib.sq_prof_marker_names.restype = i32
+    lib.sq_prof_marker_names.argtypes = [ctypes.c_char_p, sz]
     lib.sq_linear.restype = i32
     lib.sq_linear.argtypes = [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp, sz, vp]
     lib.sq_he2rna_tile_mask.restype = i32
@@ -212,8 +214,16 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def prof_enable(on):
-    check(lib().sq_prof_enable(int(bool(on))))
+def prof_enable(on, markers=False):
+    """HIP-event timing of the library's launches on / off; markers=True: sq_prof_enable(2), marker launches around every one."""
+    check(lib().sq_prof_enable(2 if (on and markers) else int(bool(on))))
+
+
+def prof_marker_names():
+    import json
+    buf = ctypes.create_string_buffer(1 << 18)
+    check(lib().sq_prof_marker_names(buf, len(buf)))
+    return json.loads(buf.value.decode())
 
 
 def prof_report():

@@ -153,7 +153,8 @@ def test_f16x3_subnormal_planes_reach_the_matrix_pipe_bit_for_bit(block_shape):
     assert float(out[1, 0]) == 2.0 ** -20 * u and float(out[2, 5]) == 2.0 ** -24 * u, "subnormal hi plane flushed"
     assert float(out[4, 7]) == ((2.0 ** -12 + 2.0 ** -24) + 2 * (2.0 ** -13 + 2.0 ** -24)) * u
     assert float(out[0, 1]) == (2.0 ** -10 + 2.0 ** -22 + 2.0 ** -30) * u and float(out[3, 0]) == (2.0 ** -3 - 2.0 ** -15) * u
-    assert torch.equal(out.float(), exact.float()), _rel_per_element(out, exact.clamp_min(1e-300))
+    bad = (out.float() != exact.float()).nonzero()
+    assert bad.numel() == 0, [(int(r), int(c), float(out[r, c]).hex(), float(exact[r, c]).hex()) for r, c in bad[:12]]
 
 
 @pytest.mark.parametrize("lo_exp,hi_exp,wlo,whi,K", [(-14, -6, -6, 0, 256), (-14, -6, -6, 0, 64), (4, 15, -8, -3, 64), (-24, -14, -3, 0, 128)])

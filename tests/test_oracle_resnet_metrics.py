@@ -61,3 +61,25 @@ def test_metrics_match_reference(golden_dir):
     assert abs(mo.mean_absolute_error(labels, preds) - float(z["mae"])) < 1e-6
     assert abs(mo.smape(labels, preds) - float(z["smape"])) < 1e-3
     assert abs(mo.mse(preds, labels) - float(z["mse"])) < 1e-5
+
+
+def test_oracle_in_double_precision_equals_the_reference_in_double_precision(golden_dir):
+    """tests/golden/fp64_truth.npz (make_fp64_truth.py: the reference's src/resnet.py network cast to double) against the oracle's
+    restatement in double on one probe patch per weight set: two fp64 evaluations of the same graph agree to ~1e-13.  Also pins
+    the recorded distance of the reference's fp32 features from the exact ones (what the -m gpu tests price every mode against)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import resnet_oracle as ro
+    from sequoia_pub_amd import synth
+    t = np.load(os.path.join(golden_dir, "fp64_truth.npz"))
+    assert 3e-7 < float(t["noise224_fp32_golden_rel_dist"]) < 1e-6 and 3e-6 < float(t["wide224_fp32_golden_rel_dist"]) < 2e-5
+    for slide, make, sd in (("noise224", lambda: synth.patches_u8(7, 1000, 224), ro.init_resnet50_state_dict(seed=99, perturb_bn=True)),
+                            ("wide224", lambda: synth.structured_patches_u8(13, 1000, 224),
+                             ro.init_resnet50_state_dict_wide(123, running_stats=np.load(os.path.join(golden_dir, "resnet50_wide_bn.npz"))))):
+        row = int(t[slide + "_patch_rows"][1])
+        x = ro.transform_patch_u8(torch.from_numpy(make()[row:row + 1])).double()
+        with torch.no_grad():
+            f = ro.forward_extract({k: v.double() for k, v in sd.items()}, x).numpy()[0]
+        ref = t[slide + "_features_fp64"][1]
+        assert np.abs(f - ref).max() <= 1e-11 * np.abs(ref).max(), slide
