@@ -68,7 +68,6 @@ struct GemmArgs {
     const void* comb_w = nullptr;      // bf16 [N / 64][64][128]: row o of head h = the combiner weight row, its first 64 columns apply to Lf
     const float* comb_rb = nullptr;    // f32 [ceil(M / comb_rpg), N] (comb_ldrb): the summary half's product + the combiner bias (Cs)
     int comb_ldrb = 0, comb_rpg = 1;
-    int x3_walk = 0;                   // gemm_x3.hip dual form: 8 = co-resident tiles as 8 x 8 squares instead of 4 x 16 strips (sq_dbg_set key 16; experiment)
     int dbg = 0;                       // ablation switches (tools/gemm_probe.py): 1 no stores, 2 no global loads after tile 0, 4 no MFMA
 };
 

@@ -578,7 +578,7 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
 
 int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return launch_reduce(a, stream); }
 
-int g_x3_small_max_k = -1, g_x3_halo = -1, g_x3_dual_walk = 0;
+int g_x3_small_max_k = -1, g_x3_halo = -1;
 extern int g_w4_waves;
 extern int g_p8_sched, g_p8_group_m, g_p8_bn, g_p8_on;
 extern "C" int sq_dbg_set(int key, int value) {
@@ -589,7 +589,6 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 4) g_tn_force_split = value;
     else if (key == 15) g_tn_ring = value;            // gemm_tn.hip: ring form on / off
     else if (key == 7) g_x3_small_max_k = value;
-    else if (key == 16) g_x3_dual_walk = value;       // gemm_x3.hip dual form: tile walk (0 strips, 8 squares)
     else if (key == 14) g_p8_on = value;             // gemm_p8.hip on / off (-1: environment)
     else if (key == 13) g_p8_bn = value;             // gemm_p8.hip: forced tile width (128 / 256)
     else if (key == 11) g_p8_group_m = value;        // gemm_p8.hip: tile rows per group of the tile walk

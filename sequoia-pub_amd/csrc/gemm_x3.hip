@@ -26,7 +26,6 @@ extern int g_x3_small_max_k;     // sq_dbg_set key 7 (tests: force one block sha
 bool sq_conv_halo_x3_eligible(const GemmArgs& a);     // conv_halo_x3.hip
 int sq_launch_conv_halo_x3(const GemmArgs& a, hipStream_t stream);
 extern int g_x3_halo;            // sq_dbg_set key 8: 0 = never take the halo-staged 3x3 kernel (tests), -1 = default
-extern int g_x3_dual_walk;       // sq_dbg_set key 16: tile walk of the dual form (0 plain, 8 squares)
 extern int g_dbg;                // sq_dbg_set key 1: ablation switches (tools/x3_probe.py) -- 1 no stores, 2 no global loads after the prologue, 4 no MFMA, 8 no fragment reads
 
 namespace {
@@ -88,19 +87,9 @@ __global__ __launch_bounds__(BM_ * 2, BM_ == 256 ? 1 : 2) void gemm_x3_kernel(co
         const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    int tm = t / tiles_n, tn = t % tiles_n;
-    if constexpr (DUAL) {
-        // experiment (sq_dbg_set key 16 = 8; round-6 review item 3c): the 64 tiles an XCD holds at a time as an 8 x 8 square of the
-        // tile grid (16 operand panels live under its L2) instead of a 4 x 16 strip (20 panels): inside every aligned band of 8
-        // tile rows the order is (column half, row, column) -- bands that do not fill (last rows, tiles_n % 16 != 0) keep the plain order
-        if (p.x3_walk == 8 && tiles_n % 16 == 0 && tm < (tiles_m & ~7)) {
-            const int band = tm >> 3, j = (tm & 7) * tiles_n + tn;          // position inside the band, row-major
-            const int sq = j >> 6, mi = (j >> 3) & 7, ni = j & 7;           // square sq of the band: 8 rows x 8 columns
-            tm = band * 8 + mi;
-            tn = sq * 8 + ni;
-        }
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
+    // (round 6: co-resident tiles of the dual form as 8 x 8 squares instead of 4 x 16 strips was measured -- 424 -> 418 us on the
+    // N = 2048 launch, nothing on the others, profiles/r06_dual_walk_ab.txt -- and not kept)
+    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
 
     const bf16_t* Ah = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* Bh = reinterpret_cast<const bf16_t*>(p.B);
@@ -605,7 +594,6 @@ int launch_x3_fmt(const GemmArgs& a, hipStream_t stream) {
 int sq_launch_gemm_x3(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     a.dbg |= g_dbg;
-    a.x3_walk = g_x3_dual_walk;
     SQ_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch == 1, "gemm_x3: empty or batched problem M=%d N=%d K=%d batch=%d", a.M, a.N, a.K, a.batch);
     SQ_REQUIRE(a.K % 8 == 0 && a.ldb % 8 == 0 && a.N % 8 == 0, "gemm_x3: K=%d / ldb=%d / N=%d must be multiples of 8", a.K, a.ldb, a.N);
     SQ_REQUIRE(a.plA != 0 && a.plB != 0 && (a.plA & 7) == 0 && (a.plB & 7) == 0, "gemm_x3: operand plane strides must be non-zero multiples of 8 elements");
