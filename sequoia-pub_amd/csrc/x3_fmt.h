@@ -3,6 +3,10 @@
 //   X3Fmt<true>:  fp16 planes  -- 11 + 11 significant bits: fp32-class (2^-23) for |v| >= 2^-3, absolute error <= 2^-25
 //                 below that (the lo plane turns subnormal), finite range |v| < 65504 (beyond: inf / NaN propagate to the
 //                 output, by design not clamped)                                                            (SQ_F16X3)
+//                 Subnormal planes: v_mfma_f32_32x32x16_f16 on gfx950 HONOURS subnormal inputs against a normal partner, bit for
+//                 bit (subnormal lo planes, subnormal hi planes, the smallest subnormal 2^-24, negative ones); the product of TWO
+//                 subnormal inputs is dropped (2^-20 x 2^-20 and 2^-24 x 2^-20 observed lost) -- that product is < 2^-28 in stored
+//                 units, an eighth of the 2^-25 above.  Pinned by tests/test_gpu_x3.py::test_f16x3_subnormal_planes_*.
 // Both feed 16-bit MFMAs at the same rate; a product is a_hi.b_hi + a_hi.b_lo + a_lo.b_hi with fp32 accumulation.
 #pragma once
 #include "sq_common.h"

@@ -153,8 +153,24 @@ def test_f16x3_subnormal_planes_reach_the_matrix_pipe_bit_for_bit(block_shape):
     assert float(out[1, 0]) == 2.0 ** -20 * u and float(out[2, 5]) == 2.0 ** -24 * u, "subnormal hi plane flushed"
     assert float(out[4, 7]) == ((2.0 ** -12 + 2.0 ** -24) + 2 * (2.0 ** -13 + 2.0 ** -24)) * u
     assert float(out[0, 1]) == (2.0 ** -10 + 2.0 ** -22 + 2.0 ** -30) * u and float(out[3, 0]) == (2.0 ** -3 - 2.0 ** -15) * u
-    bad = (out.float() != exact.float()).nonzero()
-    assert bad.numel() == 0, [(int(r), int(c), float(out[r, c]).hex(), float(exact[r, c]).hex()) for r, c in bad[:12]]
+    # ... with ONE exception the run of round 6 found: a product whose two factors are BOTH subnormal (a_hi = 2^-20 against the
+    # weight's lo plane 2^-20: 2^-40; 2^-24 x 2^-20) does not reach the accumulator, while subnormal x normal does (rows above).
+    # Such a product is < 2^-28 in the stored (scaled) units -- 2^-3 of the representation's own absolute error: harmless, but
+    # pinned here so that x3_fmt.h's statement is what the hardware does.
+    def sub(t):
+        return (t != 0) & (t.abs() < 2.0 ** -14)
+    Ah, Al = split(Af, 1)
+    Wh, Wl = split(Wf / u, 1)
+    dropped = torch.zeros_like(exact)
+    for a_, w_ in ((Ah, Wh), (Ah, Wl), (Al, Wh)):
+        dropped += (a_.double() * sub(a_)) @ (w_.double() * sub(w_)).T
+    exact_hw = exact - dropped * u
+    assert float(dropped.abs().max()) > 0 and float(dropped[1, 1]) == 2.0 ** -40
+    bad = (out.float() != exact_hw.float()).nonzero()
+    assert bad.numel() == 0, [(int(r), int(c), float(out[r, c]).hex(), float(exact_hw[r, c]).hex(), float(exact[r, c]).hex()) for r, c in bad[:12]]
+    kept = int((out.float() == exact.float()).sum()), out.numel()
+    print(f"fp16 MFMA, subnormal inputs: {kept[0]} of {kept[1]} results equal the full three-term value; subnormal x subnormal products are dropped "
+          f"({int((dropped != 0).sum())} results differ by them)")
 
 
 @pytest.mark.parametrize("lo_exp,hi_exp,wlo,whi,K", [(-14, -6, -6, 0, 256), (-14, -6, -6, 0, 64), (4, 15, -8, -3, 64), (-24, -14, -3, 0, 128)])
