@@ -24,8 +24,6 @@
 
 bool sq_conv_halo_eligible(const GemmArgs& a, int dtype);
 int sq_launch_conv_halo(const GemmArgs& a, hipStream_t stream);
-bool sq_gemm_w4_eligible(const GemmArgs& a, int dtype);
-int sq_launch_gemm_w4(const GemmArgs& a, hipStream_t stream);
 bool sq_gemm_p8_eligible(const GemmArgs& a, int dtype);
 int sq_gemm_p8_shape(const GemmArgs& a, int dtype);
 int sq_launch_gemm_p8(const GemmArgs& a, hipStream_t stream);
@@ -563,8 +561,9 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
         if (g_force_tile == 0 && a.splitk == 1 && sq_conv_halo_eligible(a, SQ_BF16)) return sq_launch_conv_halo(a, stream);
         // large plain products: 256 x 256 x 64 tile, eight phases per pair of K-tiles (gemm_p8.hip); tile 88 forces it
         if (a.splitk == 1 && a.N % 8 == 0 && !a.conv && (g_force_tile == 88 || (g_force_tile == 0 && sq_gemm_p8_eligible(a, SQ_BF16)))) return sq_launch_gemm_p8(a, stream);
-        // large products: 256 x 256 tile on four waves, 128 x 128 per wave (gemm_w4.hip); tile 55 forces it
-        if (a.splitk == 1 && a.N % 8 == 0 && (g_force_tile == 55 || (g_force_tile == 0 && sq_gemm_w4_eligible(a, SQ_BF16)))) return sq_launch_gemm_w4(a, stream);
+        // (gemm_w4.hip -- 256 x 256 tile, four 32-deep stages -- was the third engine here until round 6: after gemm_p8.hip it still took the bf16
+        // layer-4 3x3 and one strided 1x1; without it the ring kernel takes both: 218 -> 205 us and 248 -> 291 us, bf16 pipeline 80.28 vs 80.27
+        // slides/s, profiles/r06_w4_ab.txt -- deleted)
         if (a.splitk == 1 && (g_force_tile == 33 || (g_force_tile == 0 && g_use_ring && sq_gemm_ring_eligible(a, SQ_BF16))) && a.N % 8 == 0)
             return sq_launch_gemm_ring(a, stream);
     }
@@ -579,7 +578,6 @@ int launch_t(const GemmArgs& a_in, hipStream_t stream) {
 int sq_launch_splitk_reduce(const GemmArgs& a, hipStream_t stream) { return launch_reduce(a, stream); }
 
 int g_x3_small_max_k = -1, g_x3_halo = -1;
-extern int g_w4_waves;
 extern int g_p8_sched, g_p8_group_m, g_p8_bn, g_p8_on;
 extern "C" int sq_dbg_set(int key, int value) {
     if (key == 0) g_force_tile = value;
@@ -593,7 +591,6 @@ extern "C" int sq_dbg_set(int key, int value) {
     else if (key == 13) g_p8_bn = value;             // gemm_p8.hip: forced tile width (128 / 256)
     else if (key == 11) g_p8_group_m = value;        // gemm_p8.hip: tile rows per group of the tile walk
     else if (key == 10) g_p8_sched = value;          // gemm_p8.hip: schedule variant
-    else if (key == 9) g_w4_waves = value;           // gemm_w4.hip: 4 or 8 waves per 256 x 256 tile
     else if (key == 8) g_x3_halo = value;            // split-mode 3x3: 0 = implicit GEMM only     // split-mode product: K up to this takes the 128-row shape (-1 = default / environment)
     else return SQ_ERR_ARG;
     return SQ_OK;

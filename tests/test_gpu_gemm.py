@@ -211,40 +211,6 @@ def test_bad_arguments_fail_loudly():
     assert rc != 0 and b"misaligned" in lib.sq_last_error()
 
 
-@pytest.mark.parametrize("waves", [8, 4])
-@pytest.mark.parametrize("M,N,K,act", [(256 * 9 + 37, 512, 320, 2), (700, 256 + 64, 1024, 1), (3000, 768, 72, 0)])
-def test_four_stage_256_tile_variant_matches_default_tile(M, N, K, act, waves):
-    """gemm_w4.hip (256 x 256 tile, four 32-deep stages, counted waits, LDS-DMA issue spread between the MFMAs; 8 waves of
-    128 x 64 or 4 waves of 128 x 128 with the accumulators in AGPRs), forced through the experiment knob: ragged M / N / K
-    tiles, bias, bf16 residual, ReLU / GELU, bf16 output -- the same bits as the default tile (same K order, same epilogue)."""
-    _lib.require_gpu()
-    lib = _lib.lib()
-    lib.sq_dbg_set.argtypes = [ctypes.c_int, ctypes.c_int]
-    g = torch.Generator().manual_seed(M + N + waves)
-    A = torch.randn(M, K, generator=g).cuda().bfloat16()
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().bfloat16()
-    bias = torch.randn(N, generator=g).cuda()
-    res = torch.randn(M, N, generator=g).cuda().bfloat16()
-    outs = []
-    lib.sq_dbg_set(9, waves)
-    try:
-        for tile in (22, 55):
-            lib.sq_dbg_set(0, tile)
-            C = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-            _lib.check(lib.sq_linear(_lib.SQ_BF16, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(bias), _lib.ptr(res), N, _lib.SQ_BF16, act,
-                                     _lib.ptr(C), _lib.SQ_BF16, N, M, N, K, None, 0, _lib.stream_ptr()))
-            torch.cuda.synchronize()
-            outs.append(C.float())
-    finally:
-        lib.sq_dbg_set(0, 0)
-        lib.sq_dbg_set(9, -1)
-    pre = A.float() @ W.float().T + bias + res.float()
-    ref = torch.relu(pre) if act == 2 else torch.nn.functional.gelu(pre) if act == 1 else pre
-    assert torch.isfinite(outs[1]).all()
-    assert rel_err(outs[1].cpu(), ref.cpu()) < 1e-2
-    assert torch.equal(outs[0], outs[1])
-
-
 @pytest.mark.parametrize("M,N,K,act,out", [(256 * 9 + 37, 512, 320, 2, "bf16"), (700, 256 + 64, 1024, 1, "bf16"), (3000, 768, 72, 0, "f32"),
                                            (256 * 40, 1024, 4096, 0, "f32"), (256 * 70 + 37, 1024, 320, 2, "bf16"), (256 * 33, 2048, 1088, 1, "f32")])
 @pytest.mark.parametrize("sched,bn", [(0, 256), (1, 256), (1, 128)])
