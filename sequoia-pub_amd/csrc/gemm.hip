@@ -526,8 +526,7 @@ namespace {
 template <typename T>
 int launch_t(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
-    static const int env_dbg = [] { const char* e = getenv("SQ_DBG"); return e ? atoi(e) : 0; }();      // experiments only (tools/)
-    a.dbg |= g_dbg | env_dbg;
+    a.dbg |= g_dbg;
     const int epc = 16 / (int)sizeof(T);
     auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * a.batch; };
     // 128x128 whenever both extents allow it (a short grid is filled by split-K below, which measured

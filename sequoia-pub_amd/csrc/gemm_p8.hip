@@ -543,19 +543,15 @@ __global__ __launch_bounds__(NT) void gemm_p8_kernel(const GemmArgs p) {
 // Which shape of the eight-phase kernel takes the product, if any: 256 (256 x 256 tiles), 128 (256 x 128 tiles), 0 (none).  bf16,
 // plain (no convolution view), K in whole 16-byte chunks, no split-K, a vector epilogue without row bias; 256 x 256 when that
 // gives (nearly) every CU a tile, else 256 x 128 when THAT does and the product is too small for more than ~1.5 rounds of it.
-int g_p8_on = -1;                  // sq_dbg_set key 14 (tests): 0 / 1 overrides SQ_GEMM_P8
+int g_p8_on = -1;                  // sq_dbg_set key 14 (tests, probes): 0 = off, 1 = on, -1 = default (on)
 int sq_gemm_p8_shape(const GemmArgs& a, int dtype) {
     if (dtype != SQ_BF16 || a.conv || a.splitk != 1 || a.rowbias || !a.vec_epi) return 0;
     if (a.ln64_g && (a.N % 64 || !a.ln64_b)) return 0;
     if (a.ln64_g && a.gelu_grad_of) return 0;          // no epilogue of this kernel does both (LayerNorm(64) is forward, GELU' backward)
-    static int on = -1, min_tiles = 0;
+    // from 176 tiles (tools/gemm_probe.py p8m: ahead of the kernels it replaces from 192 tiles -- 24500 x 512 x 2048: 932 vs 837 TF --,
+    // level at 200 x K 1024, behind at 100); sq_dbg_set key 14 = 0 switches the kernel off (tests, probes)
+    constexpr int on = 1, min_tiles = 176;
     constexpr int min_k = 512;
-    if (on < 0) {
-        const char* e = getenv("SQ_GEMM_P8");
-        on = (e && e[0] == '0') ? 0 : 1;          // SQ_GEMM_P8=0: back to gemm_w4.hip (the A/B of tools/gemm_probe.py p8)
-        const char* mt = getenv("SQ_GEMM_P8_MIN_TILES");
-        min_tiles = mt ? atoi(mt) : 176;            // tools/gemm_probe.py p8m: ahead of the kernels it replaces from 192 tiles (24500 x 512 x 2048: 932 vs 837 TF), level at 200 x K 1024, behind at 100
-    }
     // The 256 x 128 shape is reached through sq_dbg_set key 13 only (tests, probes): on the ViS training step's 6400 x 1024 x 1024
     // products it equals the 128 x 128 kernel in isolation (23.1 vs 23.0 us; its phases hold 8 MFMAs, too few to amortise two barriers)
     // and loses in the step (3.80 vs 3.55 ms): a block that owns a whole CU leaves no room for the weight-gradient products of the helper stream.

@@ -72,8 +72,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "p8m":
         # mid-size products: where does the 256 x 256 kernel (tile 88) start to beat the engine's pick (tile 0 = the kernel it replaces
-        # below SQ_GEMM_P8_MIN_TILES tiles)?  tiles of 256 x 256 in brackets
-        os.environ["SQ_GEMM_P8"] = "0"
+        # below its minimum of 176 tiles)?  tiles of 256 x 256 in brackets
+        lib.sq_dbg_set(14, 0)          # gemm_p8.hip off (was the SQ_GEMM_P8=0 environment switch until round 6)
         for M, N, K in [(4096, 4096, 4096), (6400, 1024, 1024), (12800, 1024, 1024), (25600, 1024, 1024), (16384, 2048, 2048), (8192, 4096, 1024),
                         (24500, 2048, 1024), (24500, 512, 2048), (12800, 2048, 2048)]:
             print("tiles", ((M + 255) // 256) * (N // 256))
