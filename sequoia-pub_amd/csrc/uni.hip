@@ -503,26 +503,33 @@ extern "C" int sq_uni_forward(const sq_uni_config* c, int dtype, const float* pa
         else if (lp) hipLaunchKernelGGL(uni_attn_kernel<bf16_t>, dim3(n * H), dim3(256), att_lds, s, (const bf16_t*)w.QKV, (bf16_t*)w.O, T, H, 0.125f);
         else hipLaunchKernelGGL(uni_attn_kernel<float>, dim3(n * H), dim3(256), att_lds, s, (const float*)w.QKV, (float*)w.O, T, H, 0.125f);
         SQ_LAUNCH_CHECK();
+        // The LAST block: only the class token of its output is read (forward_head with global_pool='token', num_classes=0:
+        // compute_features_hdf5.py:125-129 takes feat_model(image) = norm(x)[:, 0]).  Keys and values need every token, everything
+        // behind the attention core is per token: the projection, LayerNorm and the MLP run on the n class rows only (row stride
+        // T D in O / X) -- 9/12 of the block's product work, 3 % of the network's, with the same per-row arithmetic.
+        const bool cls_only = l == c->depth - 1;
+        const int R = cls_only ? n : Mt;                          // rows behind the attention core
+        const int ldr = cls_only ? T * D : D;                     // their stride in O and X
         {   // x1 = x + ls1 * (o Wp^T + bp)      (gain folded into Wp / bp)
-            GemmArgs g; g.A = w.O; g.lda = D; g.a_bytes = (size_t)Mt * D * es;
+            GemmArgs g; g.A = w.O; g.lda = ldr; g.a_bytes = (size_t)Mt * D * es;
             g.B = W(L.proj_w); g.ldb = D; g.b_bytes = Wrem(L.proj_w); g.bias = Bf(L.proj_b);
-            g.res = X; g.ldres = D; g.C = X1; g.ldc = D; g.M = Mt; g.N = D; g.K = D;
+            g.res = X; g.ldres = ldr; g.C = X1; g.ldc = D; g.M = R; g.N = D; g.K = D;
             if (int e = sq_launch_gemm(g, dtype, s)) return e;
         }
-        if (int e = ln(X1, (size_t)D, L.ln2_g, L.ln2_b, w.Xn, dtype, Mt)) return e;
+        if (int e = ln(X1, (size_t)D, L.ln2_g, L.ln2_b, w.Xn, dtype, R)) return e;
         {   // h = GELU(LN(x1) W1^T + b1)
-            GemmArgs g; g.A = w.Xn; g.lda = D; g.a_bytes = (size_t)Mt * D * es;
+            GemmArgs g; g.A = w.Xn; g.lda = D; g.a_bytes = (size_t)R * D * es;
             g.B = W(L.fc1_w); g.ldb = D; g.b_bytes = Wrem(L.fc1_w); g.bias = Pf(L.fc1_b); g.act = SQ_ACT_GELU;
-            g.C = w.Hid; g.out_dtype = dtype; g.ldc = Mh; g.M = Mt; g.N = Mh; g.K = D;
+            g.C = w.Hid; g.out_dtype = dtype; g.ldc = Mh; g.M = R; g.N = Mh; g.K = D;
             if (int e = sq_launch_gemm(g, dtype, s)) return e;
         }
-        {   // x = x1 + ls2 * (h W2^T + b2)
-            GemmArgs g; g.A = w.Hid; g.lda = Mh; g.a_bytes = (size_t)Mt * Mh * es;
+        {   // x = x1 + ls2 * (h W2^T + b2)        (last block: the n class rows, packed at the head of X)
+            GemmArgs g; g.A = w.Hid; g.lda = Mh; g.a_bytes = (size_t)R * Mh * es;
             g.B = W(L.fc2_w); g.ldb = Mh; g.b_bytes = Wrem(L.fc2_w); g.bias = Bf(L.fc2_b);
-            g.res = X1; g.ldres = D; g.C = X; g.ldc = D; g.M = Mt; g.N = D; g.K = Mh;
+            g.res = X1; g.ldres = D; g.C = X; g.ldc = D; g.M = R; g.N = D; g.K = Mh;
             if (int e = sq_launch_gemm(g, dtype, s)) return e;
         }
     }
-    // features = LN(x)[cls]: the class-token row of every image (forward_head with global_pool='token', num_classes=0)
-    return ln(X, (size_t)T * D, lay.norm_g, lay.norm_b, out, SQ_F32, n);
+    // features = LN(x)[cls] (forward_head with global_pool='token', num_classes=0): the class rows, packed by the last block
+    return ln(X, (size_t)D, lay.norm_g, lay.norm_b, out, SQ_F32, n);
 }

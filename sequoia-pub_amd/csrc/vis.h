@@ -35,6 +35,7 @@ struct VisBufs {
     void* U[SQ_MAX_DEPTH];              // [M, D] T     FF pre-activation (saved only when training)
     void* H1[SQ_MAX_DEPTH];             // [M, D] T     GELU(U)
     float* skws; size_t skws_bytes;     // split-K scratch for the skinny (M = B) GEMMs
+    float* x1m;                         // [B, D] f32 token mean of the last layer's X1 (inference: the last linear map runs behind the mean)
     float* xm;                          // [B, D] f32 token mean of the last layer output
     void* xn;                           // [B, D] T   LayerNorm(xm)
     size_t bytes;

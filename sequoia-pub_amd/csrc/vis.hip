@@ -62,6 +62,7 @@ void sq_vis_bufs(const sq_vis_config& c, int dtype, int B, int save, char* base,
     }
     o->skws_bytes = (size_t)16 * B * (HD > D ? HD : D) * 4;
     o->skws = (float*)a.take(o->skws_bytes);
+    o->x1m = (float*)a.take((size_t)B * D * 4);
     o->xm = (float*)a.take((size_t)B * D * 4);
     o->xn = a.take((size_t)B * D * es);
     o->bytes = sq_align_up(a.off, 256);
@@ -278,7 +279,20 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             g.C = w.H1[s]; g.out_dtype = dtype; g.ldc = D; g.M = M; g.N = D; g.K = D;
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
-        {   // X = H1 W2^T + b2 + X1
+        if (!save && l == c->depth - 1) {
+            // Inference, last layer: only the token mean of X = H1 W2^T + b2 + X1 is read (tformer_lin.py:103), and the mean commutes
+            // with the linear map: mean_n(X) = mean_n(H1) W2^T + b2 + mean_n(X1).  One [B, D] x [D, D] product instead of the
+            // [B N, D] x [D, D] one -- 1/24 of the forward pass's large products (config 5: 13 ms of 337 per 50 000-tile slide).
+            // Means in fp32 (the kernel the summary branch uses); training (save_for_backward) keeps the per-token form.
+            if (int e = sq_k_token_mean_any(w.H1[s], dtype, w.Xbar32[s], lp ? (bf16_t*)w.Xbar[s] : nullptr, B, N, D, st)) return e;
+            if (int e = sq_k_token_mean_any(w.X1[s], stream16 ? SQ_BF16 : SQ_F32, w.x1m, nullptr, B, N, D, st)) return e;
+            GemmArgs g; g.A = w.Xbar[s]; g.lda = D; g.a_bytes = (size_t)B * D * es;
+            g.B = W(L.ff2_w); g.ldb = D; g.b_bytes = Wrem(L.ff2_w); g.bias = Pf(L.ff2_b);
+            g.res = w.x1m; g.ldres = D; g.C = w.xm; g.ldc = D; g.M = B; g.N = D; g.K = D;
+            // (no split-K workspace: the number of K slices would follow the batch size, and with it the fp32 summation order --
+            // a window's result must not depend on how the windows are batched, tests/test_gpu_spatial.py)
+            if (int e = sq_launch_gemm(g, dtype, st)) return e;
+        } else {   // X = H1 W2^T + b2 + X1
             GemmArgs g; g.A = w.H1[s]; g.lda = D; g.a_bytes = (size_t)M * D * es;
             g.B = W(L.ff2_w); g.ldb = D; g.b_bytes = Wrem(L.ff2_w); g.bias = Pf(L.ff2_b);
             g.res = w.X1[s]; g.ldres = D; g.C = Xout; g.ldc = D;
@@ -287,8 +301,10 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
             if (int e = sq_launch_gemm(g, dtype, st)) return e;
         }
     }
-    const float* Xfin = w.Xin[save ? c->depth : 0];
-    if (int e = sq_k_token_mean_any(stream16 ? w.Xin_lp[save ? c->depth : 0] : (const void*)Xfin, stream16 ? SQ_BF16 : SQ_F32, w.xm, nullptr, B, N, D, st)) return e;
+    if (save) {
+        const float* Xfin = w.Xin[c->depth];
+        if (int e = sq_k_token_mean_any(stream16 ? w.Xin_lp[c->depth] : (const void*)Xfin, stream16 ? SQ_BF16 : SQ_F32, w.xm, nullptr, B, N, D, st)) return e;
+    }       // (inference: w.xm was written by the last layer's product above)
     if (head_in)        // the caller applies the (linear) head itself, e.g. after averaging over windows: LN output in fp32
         return sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), head_in, SQ_F32, B, D, nullptr, nullptr, st);
     if (int e = sq_k_ln_rows(w.xm, Pf(lay.head_ln_g), Pf(lay.head_ln_b), w.xn, dtype, B, D, nullptr, nullptr, st)) return e;
