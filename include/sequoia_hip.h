@@ -110,6 +110,16 @@ int sq_vis_forward_ex(const sq_vis_config* cfg, int dtype, const float* params, 
                       const float* gather_src, const int32_t* gather_idx, int gather_rows, float* out, float* head_in,
                       int batch, int save_for_backward, void* workspace, size_t workspace_bytes, sq_stream_t stream);
 
+/* The gather + head_in form of sq_vis_forward_ex for the window loop of spatial_vis/visualize.py:46-82, with the first layer's
+ * local projection f (src/tformer_lin.py:20, mixers.{h}.f of layer 0, all heads) taken from per-TILE projections: f is linear in
+ * x = tile feature + pos_emb1D (tformer_lin.py:99-100), so for token (b, t)  f(x) = f_tile[gather_idx[b, t]] + f_pos[t]  with
+ *   f_tile f32 [gather_rows, nheads*64] = cache . Wf^T            (no bias; a negative index contributes a zero row)
+ *   f_pos  f32 [num_clusters, nheads*64] = pos_emb1D . Wf^T + bf
+ * computed by the caller once per slide (two sq_linear calls) instead of once per window token.  Inference only. */
+int sq_vis_forward_tiles(const sq_vis_config* cfg, int dtype, const float* params, const void* params_lp, const float* gather_src,
+                         const int32_t* gather_idx, int gather_rows, const float* f_tile, const float* f_pos, float* head_in,
+                         int batch, void* workspace, size_t workspace_bytes, sq_stream_t stream);
+
 /* Backward of ViS.forward -- replaces torch autograd over tformer_lin.py in the training loop
  * (src/vit.py:163-180 `loss.backward()`).  grad_out f32 [B, G]; grad_params: flat f32 buffer with
  * the parameter layout, fully overwritten; grad_x f32 [B, num_clusters, D] or NULL.

@@ -91,6 +91,8 @@ def _declare(lib):
     lib.sq_vis_forward.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, i32, i32, vp, sz, vp]
     lib.sq_vis_forward_ex.restype = i32
     lib.sq_vis_forward_ex.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, sz, vp]
+    lib.sq_vis_forward_tiles.restype = i32
+    lib.sq_vis_forward_tiles.argtypes = [ctypes.POINTER(VisConfig), i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, sz, vp]
     lib.sq_vis_backward_workspace_bytes.restype = sz
     lib.sq_vis_backward_workspace_bytes.argtypes = [ctypes.POINTER(VisConfig), i32, i32]
     lib.sq_vis_backward.restype = i32

@@ -15,6 +15,11 @@ int sq_k_ln_rows_any(const void* x, int in_dtype, const float* g, const float* b
                      float* mean_out, float* rstd_out, hipStream_t s);   // x fp32 or bf16
 // y = GELU(LayerNorm_64(x) * g + b) per 64-wide head group; x f32 [R, C] with C % 64 == 0, g/b [C]
 int sq_k_ln64_gelu(const float* x, const float* g, const float* b, void* y, int out_dtype, int R, int C, hipStream_t s);
+// y[(b, n), :] = GELU(LayerNorm_64(f_tile[idx[b, n], :] + f_pos[n, :]) * g + b) per 64-wide head group; a negative index is a zero row of
+// f_tile.  f_tile f32 [rows, C], f_pos f32 [N, C], idx int32 [B, N]: the first layer's local projection of a window batch taken from
+// per-TILE projections (the projection is linear in tile feature + position; sq_vis_forward_tiles)
+int sq_k_gather_ln64_gelu(const float* f_tile, const float* f_pos, const int32_t* idx, const float* g, const float* b, void* y, int out_dtype,
+                          int B, int N, int C, hipStream_t s);
 // dst = (T) src
 int sq_k_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
 int sq_k_bf16_to_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s);

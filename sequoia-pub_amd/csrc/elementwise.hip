@@ -258,6 +258,45 @@ __global__ __launch_bounds__(256) void ln64_gelu_kernel(const float4* __restrict
     }
 }
 
+// ln64_gelu_kernel with the rows built on the fly: x[(b, n), :] = f_tile[idx[b, n], :] + f_pos[n, :] (16 lanes per 64-wide group)
+template <bool FAST>
+__global__ __launch_bounds__(256) void gather_ln64_gelu_kernel(const float4* __restrict__ f_tile, const float4* __restrict__ f_pos,
+                                                               const int32_t* __restrict__ idx, const float4* __restrict__ g,
+                                                               const float4* __restrict__ b, void* __restrict__ y, int out_bf16,
+                                                               uint32_t ngroups, int C16, int N) {
+    const int sub = threadIdx.x & 15;
+    const uint32_t heads = (uint32_t)C16 >> 4;       // 64-wide groups per row
+    for (uint32_t grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; grp < ngroups; grp += (gridDim.x * blockDim.x) >> 4) {
+        const uint32_t row = grp / heads, h = grp - row * heads;
+        const int c4 = (int)(h * 16 + sub);          // float4 column inside the row
+        const int t = idx[row];
+        const uint32_t n = row % (uint32_t)N;
+        float4 v = f_pos[n * (uint32_t)C16 + c4];
+        if (t >= 0) {
+            const float4 u = f_tile[(size_t)t * C16 + c4];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.0f / 64.0f);
+        const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+        float q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
+        const float4 gg = g[c4], bb = b[c4];
+        float4 o;
+        o.x = sq_gelu<FAST>(a0 * rstd * gg.x + bb.x);
+        o.y = sq_gelu<FAST>(a1 * rstd * gg.y + bb.y);
+        o.z = sq_gelu<FAST>(a2 * rstd * gg.z + bb.z);
+        o.w = sq_gelu<FAST>(a3 * rstd * gg.w + bb.w);
+        const size_t i4 = (size_t)row * C16 + c4;
+        if (out_bf16) reinterpret_cast<uint2*>(y)[i4] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        else reinterpret_cast<float4*>(y)[i4] = o;
+    }
+}
+
 __global__ void f32_to_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, size_t n4, const float* tail_src,
                                    bf16_t* tail_dst, int tail) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,6 +490,21 @@ int sq_k_ln64_gelu(const float* x, const float* g, const float* b, void* y, int 
                        (const float4*)g, (const float4*)b, y, out_dtype == SQ_BF16, ngroups, C / 4);
     else hipLaunchKernelGGL(ln64_gelu_kernel<false>, dim3(grid_for((size_t)ngroups * 16, 256)), dim3(256), 0, s, (const float4*)x,
                        (const float4*)g, (const float4*)b, y, out_dtype == SQ_BF16, ngroups, C / 4);
+    SQ_LAUNCH_CHECK();
+    return SQ_OK;
+}
+
+int sq_k_gather_ln64_gelu(const float* f_tile, const float* f_pos, const int32_t* idx, const float* g, const float* b, void* y, int out_dtype,
+                          int B, int N, int C, hipStream_t s) {
+    SQ_REQUIRE(f_tile && f_pos && idx && g && b && y, "gather_ln64_gelu: null pointer");
+    SQ_REQUIRE(C % 64 == 0 && B >= 1 && N >= 1, "gather_ln64_gelu: C=%d must be a multiple of 64 (B=%d N=%d)", C, B, N);
+    SQ_REQUIRE((((uintptr_t)f_tile | (uintptr_t)f_pos | (uintptr_t)g | (uintptr_t)b | (uintptr_t)y) & 15) == 0, "gather_ln64_gelu: operands must be 16-byte aligned");
+    SQ_REQUIRE((size_t)B * N * (C / 64) < (1ull << 31), "gather_ln64_gelu: tensor too large for 32-bit group indexing");
+    const uint32_t ngroups = (uint32_t)((size_t)B * N * (C / 64));
+    if (out_dtype == SQ_BF16) hipLaunchKernelGGL(gather_ln64_gelu_kernel<true>, dim3(grid_for((size_t)ngroups * 16, 256)), dim3(256), 0, s, (const float4*)f_tile,
+                       (const float4*)f_pos, idx, (const float4*)g, (const float4*)b, y, 1, ngroups, C / 4, N);
+    else hipLaunchKernelGGL(gather_ln64_gelu_kernel<false>, dim3(grid_for((size_t)ngroups * 16, 256)), dim3(256), 0, s, (const float4*)f_tile,
+                       (const float4*)f_pos, idx, (const float4*)g, (const float4*)b, y, 0, ngroups, C / 4, N);
     SQ_LAUNCH_CHECK();
     return SQ_OK;
 }

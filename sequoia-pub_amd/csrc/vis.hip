@@ -144,9 +144,31 @@ extern "C" int sq_vis_forward(const sq_vis_config* c, int dtype, const float* pa
     return sq_vis_forward_ex(c, dtype, params, params_lp, x, nullptr, nullptr, 0, out, nullptr, B, save, workspace, workspace_bytes, stream_);
 }
 
+static int vis_forward_impl(const sq_vis_config* c, int dtype, const float* params, const void* params_lp, const float* x,
+                            const float* gather_src, const int32_t* gather_idx, int gather_rows, const float* f_tile, const float* f_pos,
+                            float* out, float* head_in, int B, int save, void* workspace, size_t workspace_bytes, sq_stream_t stream_);
+
 extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float* params, const void* params_lp, const float* x,
                                  const float* gather_src, const int32_t* gather_idx, int gather_rows, float* out, float* head_in,
                                  int B, int save, void* workspace, size_t workspace_bytes, sq_stream_t stream_) {
+    return vis_forward_impl(c, dtype, params, params_lp, x, gather_src, gather_idx, gather_rows, nullptr, nullptr, out, head_in, B, save,
+                            workspace, workspace_bytes, stream_);
+}
+
+// The gather form of sq_vis_forward_ex with the FIRST layer's local projection taken from per-tile projections: f(x) is linear in
+// x = tile feature + position, so F[(b, n)] = f_tile[idx[b, n]] + f_pos[n] with f_tile = cache . Wf^T computed once per TILE (50 000 rows
+// at BASELINE config 5) instead of once per window token (4.78 M rows) -- 1/24 of the sliding-window path's large products.
+extern "C" int sq_vis_forward_tiles(const sq_vis_config* c, int dtype, const float* params, const void* params_lp, const float* gather_src,
+                                    const int32_t* gather_idx, int gather_rows, const float* f_tile, const float* f_pos, float* head_in,
+                                    int B, void* workspace, size_t workspace_bytes, sq_stream_t stream_) {
+    SQ_REQUIRE(f_tile && f_pos && gather_src && gather_idx && head_in, "vis_forward_tiles: null pointer");
+    return vis_forward_impl(c, dtype, params, params_lp, nullptr, gather_src, gather_idx, gather_rows, f_tile, f_pos, nullptr, head_in, B, 0,
+                            workspace, workspace_bytes, stream_);
+}
+
+static int vis_forward_impl(const sq_vis_config* c, int dtype, const float* params, const void* params_lp, const float* x,
+                            const float* gather_src, const int32_t* gather_idx, int gather_rows, const float* f_tile, const float* f_pos,
+                            float* out, float* head_in, int B, int save, void* workspace, size_t workspace_bytes, sq_stream_t stream_) {
     if (int e = check_cfg(c)) return e;
     hipStream_t st = (hipStream_t)stream_;
     SQ_REQUIRE(dtype == SQ_F32 || dtype == SQ_BF16, "vis_forward: dtype %d", dtype);
@@ -234,6 +256,11 @@ extern "C" int sq_vis_forward_ex(const sq_vis_config* c, int dtype, const float*
         }
         if (fs) { ev_cs = fs->events[ev_next++]; SQ_HIP_CHECK(hipEventRecord(ev_cs, s2)); }
         bool combined = false;
+        if (l == 0 && f_tile) {
+            // F = f_tile[idx] + f_pos (the projection of tile feature + position, taken per tile by the caller), LayerNorm(64) + GELU in
+            // one streaming pass; the combiner follows as its own launch
+            if (int e = sq_k_gather_ln64_gelu(f_tile, f_pos, gather_idx, Pf(L.lnf_g), Pf(L.lnf_b), w.Lf[s], dtype, B, N, HD, st)) return e;
+        } else
         {   // Lf = GELU(LN64(F)),  F = X Wf^T + bf: LayerNorm + GELU in the epilogue (a head's 64 columns sit in 8
             // lanes of the staged tile); F itself is only written when the backward pass will need it
             GemmArgs g; g.A = Xin_t; g.lda = D; g.a_bytes = (size_t)M * D * es;

@@ -126,7 +126,8 @@ def window_batch_owner(n_windows, batch_windows, world):
 
 
 @torch.no_grad()
-def sliding_window_all_genes_sharded(xtf, ytf, tile_features, model, stride, literal_2d=False, batch_windows=1024, shard=None):
+def sliding_window_all_genes_sharded(xtf, ytf, tile_features, model, stride, literal_2d=False, batch_windows=1024, shard=None,
+                                     tile_projection=True):
     """visualize.py:35-102 for ONE slide over `world` ranks (BASELINE config 5's multi-GPU form; SURVEY 8e "Config 5": the
     windows of a slide are independent, visualize.py:46-52).  Every rank holds the tile-feature cache and enumerates the
     same window list; then
@@ -137,6 +138,9 @@ def sliding_window_all_genes_sharded(xtf, ytf, tile_features, model, stride, lit
          of per-tile vote sums and counts over 20 820 genes would move, and no cross-rank summation whose order could differ);
       3. tiles are dealt in chunks of HEAD_CHUNK (chunk c to rank c % world): per-tile vote over the gathered window
          vectors in visiting order, then the linear head once per tile.
+
+    In bf16 mode (``tile_projection``, default on) the first layer's local projection runs once per TILE and is gathered per window
+    token (ViS.tile_projections / sq_vis_forward_tiles): f is linear in tile feature + position.
 
     Every launch that touches a window or a tile is the launch the one-rank run makes for it (same batch, same chunk), so
     the rows a rank returns are BIT-IDENTICAL to the one-rank result.  Returns (tile_pred f32 [n_local, G], tile_ids int64
@@ -168,6 +172,9 @@ def sliding_window_all_genes_sharded(xtf, ytf, tile_features, model, stride, lit
     if streams is None or streams[0].device != dev or len(streams) != ns:
         streams = model.__dict__["_spatial_streams"] = [torch.cuda.Stream(device=dev) for _ in range(ns)]
     model._params_lp()                              # refresh the bf16 shadow on the main stream BEFORE the hand-over event:
+    # bf16 mode: layer 0's local projection once per TILE (linear in tile feature + position), gathered per window token
+    # (sq_vis_forward_tiles) -- n_tiles rows through the product instead of 100 x n_windows
+    tile_proj = model.tile_projections(feats) if (tile_projection and model.compute_dtype == _lib.SQ_BF16 and W * mem.shape[1] > n_tiles) else None
     start = torch.cuda.Event()                      # the window streams wait on `start` only and must see the finished cast
     start.record(main)
     for i, b in enumerate(range(rank, nb, world)):
@@ -177,7 +184,7 @@ def sliding_window_all_genes_sharded(xtf, ytf, tile_features, model, stride, lit
         with torch.cuda.stream(st):
             o = (b // world) * batch_windows if world > 1 else s
             n = min(batch_windows, W - s)
-            local[o:o + n] = model._run_head_inputs(feats, gather[s:s + batch_windows], slot=1 + i % ns)
+            local[o:o + n] = model._run_head_inputs(feats, gather[s:s + batch_windows], slot=1 + i % ns, tile_proj=tile_proj)
     for st in streams:
         main.wait_stream(st)
     V = max_votes_per_tile(stride)

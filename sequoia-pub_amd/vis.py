@@ -297,10 +297,38 @@ class ViS(nn.Module, PyTorchModelHubMixin):
             self._saved_gen = self.__dict__.get("_saved_gen", 0) + 1
         return out
 
-    def _run_head_inputs(self, cache, members, slot=0):
+    def tile_projections(self, cache):
+        """Layer 0's local projection f (tformer_lin.py:20, all heads) per TILE of a feature cache f32 [rows, D]: returns
+        (f_tile f32 [rows, heads*64] = cache . Wf^T, f_pos f32 [num_clusters, heads*64] = pos_emb1D . Wf^T + bf).  f is linear in
+        tile feature + position, so a window token's f(x) is f_tile[tile] + f_pos[slot] -- what sq_vis_forward_tiles gathers
+        instead of running the projection over every window token (bf16 mode; the exact fp32 mode keeps the per-token product)."""
+        _lib.require_gpu()
+        if self._C_FWD != "sq_vis_forward" or self.compute_dtype != _lib.SQ_BF16:
+            raise NotImplementedError("tile projections are the bf16 ViS sliding-window path's")
+        lay, dev = self.layout, cache.device
+        D, HD, N = self._dim(), self.cfg.nheads * 64, self.cfg.num_clusters
+        lp = self._params_lp()
+        L0 = lay.layer[0]
+        w_ptr = ctypes.c_void_p(lp.data_ptr() + 2 * L0.f_w)
+        a = cache.to(torch.bfloat16).contiguous()
+        pos = self.flat.detach()[lay.pos:lay.pos + N * D].view(N, D).to(torch.bfloat16).contiguous()
+        f_tile = torch.empty(a.shape[0], HD, dtype=torch.float32, device=dev)
+        f_pos = torch.empty(N, HD, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            for r0 in range(0, a.shape[0], 32768):         # operand extents stay below the 2 GiB buffer-descriptor limit
+                r1 = min(a.shape[0], r0 + 32768)
+                _lib.check(_lib.lib().sq_linear(self.compute_dtype, _lib.ptr(a[r0:r1]), D, w_ptr, D, None, None, 0, 0, 0,
+                                                _lib.ptr(f_tile[r0:r1]), _lib.SQ_F32, HD, r1 - r0, HD, D, None, 0, _lib.stream_ptr(dev)))
+            b_ptr = ctypes.c_void_p(self.flat.data_ptr() + 4 * L0.f_b)
+            _lib.check(_lib.lib().sq_linear(self.compute_dtype, _lib.ptr(pos), D, w_ptr, D, b_ptr, None, 0, 0, 0,
+                                            _lib.ptr(f_pos), _lib.SQ_F32, HD, N, HD, D, None, 0, _lib.stream_ptr(dev)))
+        return f_tile, f_pos
+
+    def _run_head_inputs(self, cache, members, slot=0, tile_proj=None):
         """Sliding-window form (sq_vis_forward_ex): cache f32 [n_rows, D] on the device, members int32 [B, 100] rows of
         the cache per window (-1 = zero padding).  Returns the linear head's input LayerNorm(mean_tokens X) f32 [B, D]
-        -- the window batch [B, 100, D] is gathered inside the first kernel and the head is left to the caller."""
+        -- the window batch [B, 100, D] is gathered inside the first kernel and the head is left to the caller.
+        ``tile_proj`` = tile_projections(cache): the first layer's local projection is gathered per tile (sq_vis_forward_tiles)."""
         _lib.require_gpu()
         if self._C_FWD != "sq_vis_forward":
             raise NotImplementedError("head inputs are implemented for ViS (the linear-attention aggregator)")
@@ -311,9 +339,17 @@ class ViS(nn.Module, PyTorchModelHubMixin):
         ws = self._workspace(B, False, slot)
         lp = self._params_lp()
         with torch.cuda.device(cache.device):
-            _lib.check(_lib.lib().sq_vis_forward_ex(ctypes.byref(self.cfg), self.compute_dtype, _lib.ptr(self.flat), _lib.ptr(lp), None,
-                                                    _lib.ptr(cache), _lib.ptr(members), cache.shape[0], None, _lib.ptr(out), B, 0,
-                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(cache.device)))
+            if tile_proj is not None:
+                f_tile, f_pos = tile_proj
+                if f_tile.shape != (cache.shape[0], self.cfg.nheads * 64) or f_pos.shape != (N, self.cfg.nheads * 64):
+                    raise ValueError("tile_proj does not belong to this cache / model")
+                _lib.check(_lib.lib().sq_vis_forward_tiles(ctypes.byref(self.cfg), self.compute_dtype, _lib.ptr(self.flat), _lib.ptr(lp),
+                                                           _lib.ptr(cache), _lib.ptr(members), cache.shape[0], _lib.ptr(f_tile), _lib.ptr(f_pos),
+                                                           _lib.ptr(out), B, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(cache.device)))
+            else:
+                _lib.check(_lib.lib().sq_vis_forward_ex(ctypes.byref(self.cfg), self.compute_dtype, _lib.ptr(self.flat), _lib.ptr(lp), None,
+                                                        _lib.ptr(cache), _lib.ptr(members), cache.shape[0], None, _lib.ptr(out), B, 0,
+                                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr(cache.device)))
         return out
 
     def apply_head(self, head_in, chunk=32768):

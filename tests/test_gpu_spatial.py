@@ -190,6 +190,43 @@ def test_config5_full_size_50k_tiles_probe_tiles_and_batch_invariance():
     assert diff < 1e-5
 
 
+def test_first_layer_projection_per_tile_matches_the_per_token_product():
+    """bf16 sliding-window path: layer 0's local projection taken once per TILE and gathered per window token
+    (ViS.tile_projections + sq_vis_forward_tiles: f(tile feature + position) = f_tile[tile] + f_pos[slot]) against the per-token
+    product of sq_vis_forward_ex on the same windows -- holes (zero-padded windows), the model at its real size.  The two differ by
+    where the bf16 rounding of the operand happens (feature and position separately vs their sum): bf16-level, far inside the
+    mode's distance from the fp32 oracle (5e-3)."""
+    _lib.require_gpu()
+    from sequoia_pub_amd.spatial import sliding_window_all_genes_sharded
+    nx, ny = 36, 25
+    xs, ys = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    keep = np.random.default_rng(3).random(nx * ny) < 0.9
+    x, y = xs.ravel()[keep], ys.ravel()[keep]
+    cfg = dict(num_outputs=20820, input_dim=1024, depth=6, nheads=16, dimensions_f=64, dimensions_s=64, dimensions_c=64)
+    sd = vis_oracle.perturb_norm_params(vis_oracle.init_vis_state_dict(**cfg, seed=41), seed=42)
+    m = ViS(**cfg, device="cuda:0", compute_dtype="bf16")
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    feats = torch.randn(x.size, 1024, generator=torch.Generator().manual_seed(43)).cuda()
+    a, _, va = sliding_window_all_genes_sharded(x, y, feats, m, 1, batch_windows=256, tile_projection=True)
+    b, _, vb = sliding_window_all_genes_sharded(x, y, feats, m, 1, batch_windows=256, tile_projection=False)
+    assert torch.equal(va, vb) and int((va > 0).sum()) > 0.9 * x.size
+    cov = va > 0
+    diff = float((a[cov] - b[cov]).abs().max() / b[cov].abs().max())
+    # the projections themselves against torch on the joined operands
+    f_tile, f_pos = m.tile_projections(feats)
+    wf = torch.cat([sd[f"transformer.layers.0.0.mixers.{h}.f.weight"] for h in range(16)]).cuda()
+    bf = torch.cat([sd[f"transformer.layers.0.0.mixers.{h}.f.bias"] for h in range(16)]).cuda()
+    ref_tile = feats.bfloat16().double() @ wf.bfloat16().double().T
+    ref_pos = sd["pos_emb1D"].cuda().bfloat16().double() @ wf.bfloat16().double().T + bf.double()
+    e_t = float((f_tile.double() - ref_tile).abs().max() / ref_tile.abs().max())
+    e_p = float((f_pos.double() - ref_pos).abs().max() / ref_pos.abs().max())
+    print(f"layer-0 projection per tile vs per window token ({int(cov.sum())} covered tiles, bf16): max difference {diff:.2e} of max; "
+          f"f_tile vs fp64 on the bf16 operands {e_t:.1e}, f_pos {e_p:.1e}")
+    assert e_t < 1e-5 and e_p < 1e-5
+    assert diff < 5e-3
+
+
 def test_visualize_cli_on_a_synthetic_slide(tmp_path):
     """spatial_vis/visualize.py:104-307 end to end: an in-memory 20x slide, mask -> valid tiles -> ResNet feature cache ->
     two-fold ViS ensemble and one HE2RNA fold -> stride-1 CSV; the CSV equals the library calls on the same cache."""
