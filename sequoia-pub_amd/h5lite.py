@@ -220,7 +220,10 @@ class File:
         sid = lib.H5Screate_simple(arr.ndim, dims, None)
         # h5py's default (track_times=False): no creation / modification stamps in the object header, so a file's bytes are a
         # function of its contents -- the files of a sharded run can be compared with the one-rank run's byte for byte
-        dcpl = lib.H5Pcreate(hid_t.in_dll(lib, "H5P_CLS_DATASET_CREATE_ID_g").value)
+        try:
+            dcpl = lib.H5Pcreate(hid_t.in_dll(lib, "H5P_CLS_DATASET_CREATE_ID_g").value)
+        except ValueError:                       # a build that does not export the property-list class id: default creation properties
+            dcpl = -1
         if dcpl >= 0:
             lib.H5Pset_obj_track_times(dcpl, 0)
         did = lib.H5Dcreate2(self._fid, name.encode(), tid, sid, 0, max(dcpl, 0), 0)
