@@ -84,3 +84,39 @@ def test_one_rank_gather_map_is_the_identity_and_shard_arguments_are_checked():
         _shard_info((2, 2))
     with pytest.raises(RuntimeError):
         _shard_info((0, 2))                        # no process group in this process
+
+
+class _FakeExtractor:
+    """Stands in for the patch embedder on the CPU: a deterministic function of the tile's pixels, 1024 columns."""
+    def extract_patches_u8(self, t):
+        f = t.reshape(t.shape[0], -1).float()
+        return torch.stack([f.mean(1), f.std(1), f[:, 0], f[:, -1]], 1).repeat(1, 256)
+
+
+def _embed_worker(rank, world, port, n_tiles, chunk, out_dir):
+    import os
+    import pandas as pd
+    import torch.distributed as dist
+    from sequoia_pub_amd.cli.visualize import embed_tiles
+    from sequoia_pub_amd.patchgen import ArraySlide
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = np.random.RandomState(2)
+    slide = ArraySlide([rs.randint(0, 256, (64, 16 * n_tiles + 16, 3), dtype=np.uint8)])
+    df = pd.DataFrame({"xcoord": np.arange(n_tiles) * 16, "ycoord": np.zeros(n_tiles, dtype=int)})
+    one = embed_tiles(slide, df, 16, 16, _FakeExtractor(), "cpu", chunk=chunk)
+    both = embed_tiles(slide, df, 16, 16, _FakeExtractor(), "cpu", chunk=chunk, shard=(rank, world))
+    assert both.shape == one.shape == (n_tiles, 1024) and torch.equal(both, one), "the gathered cache differs from the one-rank cache"
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_tiles,chunk", [(23, 4), (8, 4), (3, 4), (0, 4)])
+def test_tile_cache_embedded_over_two_gloo_ranks_equals_the_one_rank_cache(tmp_path, n_tiles, chunk):
+    """cli/visualize.embed_tiles under two ranks (CPU, gloo, a stand-in extractor): tile chunks dealt round-robin, one all-gather,
+    rows back in df order -- ragged last chunk, one chunk per rank, a rank without a chunk, a slide without valid tiles."""
+    import os
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() + 31 * n_tiles + chunk) % 2000
+    mp.spawn(_embed_worker, args=(2, port, n_tiles, chunk, str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").read_text() == "ok" for r in range(2))
